@@ -1,0 +1,375 @@
+"""CPU restatement (fp32, plain torch tensor ops) of the src/clip_whisper hot path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Every function cites the reference
+file:line it restates.  `HF:` = transformers 5.15.0 (the third-party library where the
+arithmetic lives).  Parity of this restatement is pinned by
+`tests/golden/*.npz`, produced by oracle/make_golden.py from the reference's own
+`ClipWhisperModel.encode/forward/generate` driving config-instantiated HF modules.
+LoRA (peft) and WER (jiwer) are restated from their published definitions because neither
+library is installed here: those two are "parity unpinned" against the real libraries.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- primitives
+def layer_norm(x, w, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def softmax_attention(q, k, v, scale, causal):
+    """q,k,v [B,H,T,hd] -> [B,T,H*hd].  HF eager_attention_forward (whisper :215-238, clip :259-277,
+    llama eager path): softmax(QK^T*scale + mask) V in fp32."""
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if causal:
+        T, S = s.shape[-2:]
+        mask = torch.ones(T, S, dtype=torch.bool).tril(diagonal=S - T)
+        s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, v)
+    return o.transpose(1, 2).reshape(o.shape[0], o.shape[2], -1)
+
+
+# --------------------------------------------------------------------------- Whisper encoder
+def whisper_encoder(sd, c, mel):
+    """HF:models/whisper/modeling_whisper.py:592-646 (layer :379-413, attention :284-357).
+    mel [B,80,3000] -> [B,1500,d]."""
+    if mel.shape[-1] != 2 * c.n_ctx:
+        raise ValueError(f"Whisper expects the mel input features to be of length {2 * c.n_ctx}, but found {mel.shape[-1]}")
+    x = gelu_erf(F.conv1d(mel, sd["encoder.conv1.weight"], sd["encoder.conv1.bias"], padding=1))
+    x = gelu_erf(F.conv1d(x, sd["encoder.conv2.weight"], sd["encoder.conv2.bias"], stride=2, padding=1))
+    x = x.permute(0, 2, 1) + sd["encoder.embed_positions.weight"]
+    B, T, d = x.shape
+    H = c.heads
+    hd = d // H
+    for i in range(c.layers):
+        L = f"encoder.layers.{i}."
+        h = layer_norm(x, sd[L + "self_attn_layer_norm.weight"], sd[L + "self_attn_layer_norm.bias"])
+        q = (h @ sd[L + "self_attn.q_proj.weight"].T + sd[L + "self_attn.q_proj.bias"]) * (hd ** -0.5)
+        k = h @ sd[L + "self_attn.k_proj.weight"].T
+        v = h @ sd[L + "self_attn.v_proj.weight"].T + sd[L + "self_attn.v_proj.bias"]
+        sp = lambda t: t.view(B, T, H, hd).transpose(1, 2)
+        a = softmax_attention(sp(q), sp(k), sp(v), 1.0, causal=False)
+        x = x + (a @ sd[L + "self_attn.out_proj.weight"].T + sd[L + "self_attn.out_proj.bias"])
+        h = layer_norm(x, sd[L + "final_layer_norm.weight"], sd[L + "final_layer_norm.bias"])
+        h = gelu_erf(h @ sd[L + "fc1.weight"].T + sd[L + "fc1.bias"])
+        x = x + (h @ sd[L + "fc2.weight"].T + sd[L + "fc2.bias"])
+    return layer_norm(x, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"])
+
+
+# --------------------------------------------------------------------------- CLIP vision tower
+def clip_vision_cls(sd, c, frames):
+    """HF:models/clip/modeling_clip.py:641-656 (embeddings :202-218, layer :362-384, attn :297-335,
+    MLP :346-350) followed by the reference's CLS pick WITHOUT post_layernorm
+    (clip_whisper_model.py:1138-1142).  frames [N,3,H,W] -> [N,d]."""
+    N = frames.shape[0]
+    d, H = c.hidden, c.heads
+    hd = d // H
+    if frames.shape[-1] != c.image or frames.shape[-2] != c.image:
+        raise ValueError(f"Input image size ({frames.shape[-2]}*{frames.shape[-1]}) doesn't match model ({c.image}*{c.image}).")
+    pe = F.conv2d(frames, sd["embeddings.patch_embedding.weight"], stride=c.patch)  # [N,d,g,g]
+    pe = pe.flatten(2).transpose(1, 2)
+    cls = sd["embeddings.class_embedding"].expand(N, 1, d)
+    x = torch.cat([cls, pe], dim=1) + sd["embeddings.position_embedding.weight"]
+    x = layer_norm(x, sd["pre_layrnorm.weight"], sd["pre_layrnorm.bias"], c.eps)
+    T = x.shape[1]
+    for i in range(c.layers):
+        L = f"encoder.layers.{i}."
+        h = layer_norm(x, sd[L + "layer_norm1.weight"], sd[L + "layer_norm1.bias"], c.eps)
+        q = h @ sd[L + "self_attn.q_proj.weight"].T + sd[L + "self_attn.q_proj.bias"]
+        k = h @ sd[L + "self_attn.k_proj.weight"].T + sd[L + "self_attn.k_proj.bias"]
+        v = h @ sd[L + "self_attn.v_proj.weight"].T + sd[L + "self_attn.v_proj.bias"]
+        sp = lambda t: t.view(N, T, H, hd).transpose(1, 2)
+        a = softmax_attention(sp(q), sp(k), sp(v), hd ** -0.5, causal=False)
+        x = x + (a @ sd[L + "self_attn.out_proj.weight"].T + sd[L + "self_attn.out_proj.bias"])
+        h = layer_norm(x, sd[L + "layer_norm2.weight"], sd[L + "layer_norm2.bias"], c.eps)
+        h = quick_gelu(h @ sd[L + "mlp.fc1.weight"].T + sd[L + "mlp.fc1.bias"])
+        x = x + (h @ sd[L + "mlp.fc2.weight"].T + sd[L + "mlp.fc2.bias"])
+    return x[:, 0]
+
+
+# --------------------------------------------------------------------------- reference glue
+def connector(sd, x):
+    """SimpleModalityConnector.forward, modality_connector.py:16-20,43-44."""
+    return x @ sd["linear.weight"].T + sd["linear.bias"]
+
+
+def pad_or_truncate(x, target_len):
+    """clip_whisper_model.py:320-374 (3-D branch)."""
+    cur = x.shape[1]
+    if cur == target_len:
+        return x
+    if cur > target_len:
+        return x[:, :target_len]
+    pad = torch.zeros(x.shape[0], target_len - cur, x.shape[2], dtype=x.dtype)
+    return torch.cat([x, pad], dim=1)
+
+
+def adaptive_projection(x, target_len, training=True):
+    """clip_whisper_model.py:621-707.  Longer -> AdaptiveAvgPool1d(target) (window i =
+    [floor(i*L/T), ceil((i+1)*L/T))); shorter -> linear interpolation, align_corners=True
+    (train: F.interpolate; eval: explicit floor/ceil gather -- same formula)."""
+    B, L, D = x.shape
+    if L == target_len:
+        return x
+    if L > target_len:
+        out = torch.empty(B, target_len, D, dtype=x.dtype)
+        for i in range(target_len):
+            s = (i * L) // target_len
+            e = -((-(i + 1) * L) // target_len)
+            out[:, i] = x[:, s:e].mean(dim=1)
+        return out
+    if training:
+        # F.interpolate(mode='linear', align_corners=True): src = i*(L-1)/(T-1)
+        if target_len == 1:
+            return x[:, :1]
+        scale = (L - 1) / (target_len - 1)
+        idx = torch.arange(target_len, dtype=torch.float32) * scale
+    else:
+        idx = torch.linspace(0, L - 1, target_len)
+    lo = idx.floor().long()
+    hi = torch.clamp(idx.ceil().long(), max=L - 1) if not training else torch.clamp(lo + 1, max=L - 1)
+    a = (idx - lo.float()).view(1, -1, 1)
+    return x[:, lo] * (1 - a) + x[:, hi] * a
+
+
+def adapt_mask(mask, target_len):
+    """clip_whisper_model.py:709-736."""
+    B, L = mask.shape
+    if L == target_len:
+        return mask
+    if L > target_len:
+        return mask[:, :target_len]
+    return torch.cat([mask, torch.ones(B, target_len - L, dtype=mask.dtype)], dim=1)
+
+
+def encode(W, cfg, audio=None, video=None, prompt=None):
+    """ClipWhisperModel.encode, clip_whisper_model.py:407-462 with encode_audio :1067-1106,
+    encode_video :1108-1146, _embed_prompt :464-487."""
+    a = v = None
+    if audio is not None:
+        if audio.dim() != 3 or audio.shape[1] != 80:
+            raise ValueError(f"Audio input should have shape [batch_size, 80, time_steps], but got {tuple(audio.shape)}")
+        a = connector(W["audio_connector"], whisper_encoder(W["whisper"], cfg.whisper, audio.float()))
+    if video is not None:
+        if video.dim() != 5 or video.shape[2] != 3:
+            raise ValueError(f"Video input should have shape [batch_size, frames, 3, height, width], but got {tuple(video.shape)}")
+        B, Fr = video.shape[:2]
+        cls = clip_vision_cls(W["clip"], cfg.clip, video.float().reshape(B * Fr, 3, video.shape[3], video.shape[4]))
+        v = connector(W["video_connector"], cls.view(B, Fr, -1))
+    if a is not None and v is not None:
+        L = min(cfg.max_seq_len, max(a.shape[1], v.shape[1]))
+        out = cfg.fusion_scale * pad_or_truncate(a, L) + (1 - cfg.fusion_scale) * pad_or_truncate(v, L)
+    elif a is not None:
+        out = a
+    elif v is not None:
+        out = v
+    else:
+        raise ValueError("No valid inputs provided - both audio and video are None")
+    if prompt is not None:
+        ids = prompt[:, : cfg.max_prompt_len]
+        out = torch.cat([W["llama"]["model.embed_tokens.weight"][ids], out], dim=1)
+    mask = torch.ones(out.shape[0], out.shape[1], dtype=torch.long)
+    return out, mask
+
+
+# --------------------------------------------------------------------------- Llama + LoRA
+def rms_norm(x, w, eps):
+    """HF:models/llama/modeling_llama.py:62-67."""
+    var = x.pow(2).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(var + eps))
+
+
+def rope_cos_sin(positions, hd, theta):
+    """HF:models/llama/modeling_llama.py:70-126 (default rope)."""
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = positions.float()[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def apply_rope(x, cos, sin):
+    """x [B,H,T,hd]; HF:...modeling_llama.py:129-160 (rotate_half convention)."""
+    h = x.shape[-1] // 2
+    rot = torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+    return x * cos + rot * sin
+
+
+def lora_linear(x, w, lora, key, scale):
+    """peft lora.Linear (dropout=identity here): W x + scale * B(A x).  Reference wrap:
+    clip_whisper_model.py:961-1005.  Parity unpinned against real peft (not installed)."""
+    y = x @ w.T
+    if lora is not None and (key + ".lora_A") in lora:
+        y = y + scale * ((x @ lora[key + ".lora_A"].T) @ lora[key + ".lora_B"].T)
+    return y
+
+
+def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0):
+    """LlamaModel.forward, HF:models/llama/modeling_llama.py:366-419; layer :284-324; attn :236-281.
+    x [B,T,d] inputs_embeds.  `past` = optional list of (k,v) per layer (KV cache), updated in place."""
+    B, T, d = x.shape
+    H, hd = c.heads, c.head_dim
+    cos, sin = rope_cos_sin(torch.arange(pos0, pos0 + T), hd, c.theta)
+    scale = lc.scale if lc is not None else 0.0
+    for i in range(c.layers):
+        L = f"model.layers.{i}."
+        K = f"layers.{i}."
+        h = rms_norm(x, sd[L + "input_layernorm.weight"], c.eps)
+        q = lora_linear(h, sd[L + "self_attn.q_proj.weight"], lora, K + "q_proj", scale)
+        k = lora_linear(h, sd[L + "self_attn.k_proj.weight"], lora, K + "k_proj", scale)
+        v = lora_linear(h, sd[L + "self_attn.v_proj.weight"], lora, K + "v_proj", scale)
+        sp = lambda t: t.view(B, T, H, hd).transpose(1, 2)
+        q, k, v = apply_rope(sp(q), cos, sin), apply_rope(sp(k), cos, sin), sp(v)
+        if past is not None:
+            if past[i] is not None:
+                k = torch.cat([past[i][0], k], dim=2)
+                v = torch.cat([past[i][1], v], dim=2)
+            past[i] = (k, v)
+        a = softmax_attention(q, k, v, hd ** -0.5, causal=True)
+        x = x + lora_linear(a, sd[L + "self_attn.o_proj.weight"], lora, K + "o_proj", scale)
+        h = rms_norm(x, sd[L + "post_attention_layernorm.weight"], c.eps)
+        g = h @ sd[L + "mlp.gate_proj.weight"].T
+        u = h @ sd[L + "mlp.up_proj.weight"].T
+        x = x + (F.silu(g) * u) @ sd[L + "mlp.down_proj.weight"].T
+    return rms_norm(x, sd["model.norm.weight"], c.eps)
+
+
+def causal_lm_loss(logits, labels):
+    """HF:loss/loss_utils.py:49-71: labels padded with -100 then shifted by one; mean CE over
+    non-ignored positions in fp32."""
+    B, T, V = logits.shape
+    shift = torch.cat([labels[:, 1:], torch.full((B, 1), -100, dtype=labels.dtype)], dim=1)
+    return F.cross_entropy(logits.float().view(-1, V), shift.reshape(-1), ignore_index=-100, reduction="mean")
+
+
+def prepare_llm_inputs(W, cfg, audio, video, prompt, labels, training):
+    """The part of ClipWhisperModel.forward before the LLM call, clip_whisper_model.py:489-598."""
+    x, mask = encode(W, cfg, audio, video, prompt)
+    if labels is not None:
+        labels = labels.clone()
+        labels[labels == cfg.pad_token_id] = -100
+        if labels.shape[1] != x.shape[1]:
+            if training:
+                x = adaptive_projection(x, labels.shape[1], training=True)
+                mask = adapt_mask(mask, labels.shape[1])
+            elif labels.shape[1] > x.shape[1]:
+                labels = labels[:, : x.shape[1]]
+            else:
+                pad = torch.full((labels.shape[0], x.shape[1] - labels.shape[1]), -100, dtype=labels.dtype)
+                labels = torch.cat([labels, pad], dim=1)
+    return x, mask, labels
+
+
+def forward(W, cfg, audio=None, video=None, prompt=None, labels=None, training=True, return_loss=True):
+    """ClipWhisperModel.forward, clip_whisper_model.py:489-619.  Returns {"loss","logits"}."""
+    x, mask, labels = prepare_llm_inputs(W, cfg, audio, video, prompt, labels if return_loss else None, training)
+    h = llama_hidden(W["llama"], W.get("lora"), cfg.llama, cfg.lora, x)
+    logits = h @ W["llama"]["lm_head.weight"].T
+    out = {"logits": logits}
+    if return_loss and labels is not None:
+        out["loss"] = causal_lm_loss(logits, labels)
+    return out
+
+
+def train_step_grads(W, cfg, audio, video, prompt, labels):
+    """One forward+backward of the reference's training step (trainer/clip_whisper_trainer.py:433-456)
+    with freeze_encoders=True: encoders+connectors run under no_grad (clip_whisper_model.py:1096-1106),
+    so only the LoRA tensors receive gradients."""
+    with torch.no_grad():
+        x, mask, lab = prepare_llm_inputs(W, cfg, audio, video, prompt, labels, training=True)
+    lora = {k: v.clone().requires_grad_(True) for k, v in W["lora"].items()}
+    h = llama_hidden(W["llama"], lora, cfg.llama, cfg.lora, x)
+    logits = h @ W["llama"]["lm_head.weight"].T
+    loss = causal_lm_loss(logits, lab)
+    loss.backward()
+    return loss.detach(), logits.detach(), {k: v.grad for k, v in lora.items()}
+
+
+def generate(W, cfg, audio=None, video=None, prompt=None, max_new_tokens=100, eos_token_id=None):
+    """ClipWhisperModel.generate, clip_whisper_model.py:1240-1348 -> HF GenerationMixin greedy search
+    (do_sample=False) on inputs_embeds with a KV cache; returns new tokens only [B, <=max_new_tokens].
+    After a row emits eos it is padded with pad_token_id (HF greedy `unfinished_sequences` rule)."""
+    with torch.no_grad():
+        x, mask = encode(W, cfg, audio, video, prompt)
+        sd, c = W["llama"], cfg.llama
+        past = [None] * c.layers
+        h = llama_hidden(sd, W.get("lora"), c, cfg.lora, x, past=past, pos0=0)
+        pos = x.shape[1]
+        B = x.shape[0]
+        unfinished = torch.ones(B, dtype=torch.bool)
+        out = []
+        for _ in range(max_new_tokens):
+            logits = h[:, -1] @ sd["lm_head.weight"].T
+            nxt = logits.argmax(-1)
+            if eos_token_id is not None:
+                nxt = torch.where(unfinished, nxt, torch.full_like(nxt, cfg.pad_token_id))
+                unfinished = unfinished & (nxt != eos_token_id)
+            out.append(nxt)
+            if eos_token_id is not None and not unfinished.any():
+                break
+            h = llama_hidden(sd, W.get("lora"), c, cfg.lora, sd["model.embed_tokens.weight"][nxt][:, None], past=past, pos0=pos)
+            pos += 1
+        return torch.stack(out, dim=1)
+
+
+# --------------------------------------------------------------------------- optimizer
+def clip_grad_norm_(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ as used at trainer/clip_whisper_trainer.py:458:
+    total L2 norm; coef = max_norm/(norm+1e-6) clamped to 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.01):
+    """torch.optim.AdamW (non-amsgrad) single-tensor rule; hyper-parameters from
+    trainer/clip_whisper_trainer.py:171-232.  `step` is 1-based."""
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def cosine_lr(base_lr, step, t_max, eta_min=0.0):
+    """CosineAnnealingLR closed form (trainer/clip_whisper_trainer.py:210-230, no-warmup branch)."""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * step / t_max)) / 2
+
+
+# --------------------------------------------------------------------------- WER
+def wer(refs, hyps):
+    """jiwer.wer(refs, hyps) restated (scripts/clip_whisper/decode.py:30-37, use sites :597,:658):
+    corpus-level (S+D+I)/N over whitespace-split words, no normalisation.  Parity unpinned
+    against jiwer (not installed; known-answer tests in tests/test_oracle.py)."""
+    if isinstance(refs, str):
+        refs, hyps = [refs], [hyps]
+    errs = n = 0
+    for r, h in zip(refs, hyps):
+        rw, hw = r.split(), h.split()
+        n += len(rw)
+        prev = list(range(len(hw) + 1))
+        for i in range(1, len(rw) + 1):
+            cur = [i] + [0] * len(hw)
+            for j in range(1, len(hw) + 1):
+                cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (rw[i - 1] != hw[j - 1]))
+            prev = cur
+        errs += prev[len(hw)]
+    return errs / n if n else float("inf")
