@@ -1,0 +1,328 @@
+"""Host-side owners of device weights/workspaces for the three model-level C-ABI engines.
+
+Weights arrive as HuggingFace-named state dicts (the modules the reference instantiates:
+clip_whisper_model.py:864-1019), are re-laid-out once for the HIP kernels (fused qkv / gate-up, im2col-ordered
+conv weights, transposed images for the dX GEMMs) and stay resident in HBM.  All compute is in libavllm.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from . import ops
+
+
+class Workspace:
+    """One growable byte buffer handed to the C ABI as scratch (the library never allocates)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes: int):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def _dev(t, dtype, device):
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+def _pad_cols(w2d, kpad):
+    if w2d.shape[1] == kpad:
+        return w2d
+    out = torch.zeros(w2d.shape[0], kpad, dtype=w2d.dtype, device=w2d.device)
+    out[:, : w2d.shape[1]] = w2d
+    return out
+
+
+def _enc_layers(sd, prefix_fmt, n, names, dtype, device, keep):
+    """Build the EncLayer array for a pre-LN encoder; `names` maps our fields to HF suffixes."""
+    arr = (L.EncLayer * n)()
+    for i in range(n):
+        p = prefix_fmt.format(i)
+        g = lambda k: sd[p + k]
+        q, k_, v = g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight")
+        d = q.shape[0]
+        bq = g(names["q"] + ".bias")
+        bk = sd.get(p + names["k"] + ".bias")
+        if bk is None:
+            bk = torch.zeros(d, dtype=bq.dtype, device=bq.device)     # Whisper k_proj has no bias (HF whisper :276)
+        bv = g(names["v"] + ".bias")
+        t = {
+            "ln1_w": g(names["ln1"] + ".weight"), "ln1_b": g(names["ln1"] + ".bias"),
+            "wqkv": torch.cat([q, k_, v], 0), "bqkv": torch.cat([bq, bk, bv], 0),
+            "wo": g(names["o"] + ".weight"), "bo": g(names["o"] + ".bias"),
+            "ln2_w": g(names["ln2"] + ".weight"), "ln2_b": g(names["ln2"] + ".bias"),
+            "w1": g(names["fc1"] + ".weight"), "b1": g(names["fc1"] + ".bias"),
+            "w2": g(names["fc2"] + ".weight"), "b2": g(names["fc2"] + ".bias"),
+        }
+        for k, val in t.items():
+            dv = _dev(val, dtype, device)
+            keep.append(dv)
+            setattr(arr[i], k, dv.data_ptr())
+    return arr
+
+
+class WhisperEngine:
+    """avllm_whisper_encoder_fwd: mel f32 [B,80,2*n_ctx] -> [B,n_ctx,d]."""
+
+    def __init__(self, sd, cfg, dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.keep = []
+        d = cfg.d_model
+        k1pad = (3 * cfg.n_mels + 63) // 64 * 64
+        w = L.Whisper()
+        w.dtype, w.d, w.heads, w.layers, w.ffn, w.n_mels, w.n_ctx, w.k1pad = (
+            L.F32 if dtype == torch.float32 else L.BF16, d, cfg.heads, cfg.layers, cfg.ffn, cfg.n_mels, cfg.n_ctx, k1pad)
+        c1 = _pad_cols(sd["encoder.conv1.weight"].reshape(d, 3 * cfg.n_mels), k1pad)         # column c*3+kw
+        c2 = sd["encoder.conv2.weight"].permute(0, 2, 1).reshape(d, 3 * d)                   # column kw*d+c
+        for name, val in (("conv1_w", c1), ("conv1_b", sd["encoder.conv1.bias"]), ("conv2_w", c2),
+                          ("conv2_b", sd["encoder.conv2.bias"]), ("pos", sd["encoder.embed_positions.weight"]),
+                          ("lnf_w", sd["encoder.layer_norm.weight"]), ("lnf_b", sd["encoder.layer_norm.bias"])):
+            dv = _dev(val, dtype, device)
+            self.keep.append(dv)
+            setattr(w, name, dv.data_ptr())
+        names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
+                     ln1="self_attn_layer_norm", ln2="final_layer_norm", fc1="fc1", fc2="fc2")
+        self.layers = _enc_layers(sd, "encoder.layers.{}.", cfg.layers, names, dtype, device, self.keep)
+        w.layer = C.cast(self.layers, C.POINTER(L.EncLayer))
+        self.desc = w
+        self.ws = Workspace(device)
+
+    def forward(self, mel):
+        if mel.dim() != 3 or mel.shape[1] != self.cfg.n_mels:
+            raise ValueError(f"Audio input should have shape [batch_size, {self.cfg.n_mels}, time_steps], but got {tuple(mel.shape)}")
+        if mel.shape[-1] != 2 * self.cfg.n_ctx:
+            raise ValueError(f"Whisper expects the mel input features to be of length {2 * self.cfg.n_ctx}, but found {mel.shape[-1]}")
+        lib = L.load()
+        mel = mel.to(device=self.device, dtype=torch.float32).contiguous()
+        B = mel.shape[0]
+        out = torch.empty(B, self.cfg.n_ctx, self.cfg.d_model, device=self.device, dtype=self.dtype)
+        n = lib.avllm_whisper_workspace_bytes(C.byref(self.desc), B)
+        ws = self.ws.get(n)
+        L.check(lib.avllm_whisper_encoder_fwd(C.byref(self.desc), L.ptr(mel), B, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return out
+
+
+class ClipEngine:
+    """avllm_clip_vision_cls_fwd: frames f32 [N,3,S,S] -> CLS of last_hidden_state [N,d] (no post_layernorm)."""
+
+    def __init__(self, sd, cfg, dtype=torch.bfloat16, device="cuda", chunk_frames=0):
+        sd = {k[len("vision_model."):] if k.startswith("vision_model.") else k: v for k, v in sd.items()}
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.chunk = chunk_frames
+        self.keep = []
+        d = cfg.hidden
+        kpad = (3 * cfg.patch * cfg.patch + 63) // 64 * 64
+        c = L.Clip()
+        c.dtype, c.d, c.heads, c.layers, c.ffn, c.image, c.patch, c.tokens = (
+            L.F32 if dtype == torch.float32 else L.BF16, d, cfg.heads, cfg.layers, cfg.mlp, cfg.image, cfg.patch, cfg.tokens)
+        c.eps = cfg.eps
+        pw = _pad_cols(sd["embeddings.patch_embedding.weight"].reshape(d, -1), kpad)
+        for name, val in (("patch_w", pw), ("class_emb", sd["embeddings.class_embedding"]),
+                          ("pos", sd["embeddings.position_embedding.weight"]), ("pre_ln_w", sd["pre_layrnorm.weight"]),
+                          ("pre_ln_b", sd["pre_layrnorm.bias"])):
+            dv = _dev(val, dtype, device)
+            self.keep.append(dv)
+            setattr(c, name, dv.data_ptr())
+        names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
+                     ln1="layer_norm1", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+        self.layers = _enc_layers(sd, "encoder.layers.{}.", cfg.layers, names, dtype, device, self.keep)
+        c.layer = C.cast(self.layers, C.POINTER(L.EncLayer))
+        self.desc = c
+        self.ws = Workspace(device)
+
+    def forward(self, frames):
+        if frames.dim() != 4 or frames.shape[1] != 3:
+            raise ValueError(f"frames should have shape [N, 3, H, W], but got {tuple(frames.shape)}")
+        if frames.shape[-1] != self.cfg.image or frames.shape[-2] != self.cfg.image:
+            raise ValueError(f"Input image size ({frames.shape[-2]}*{frames.shape[-1]}) doesn't match model ({self.cfg.image}*{self.cfg.image}).")
+        lib = L.load()
+        frames = frames.to(device=self.device, dtype=torch.float32).contiguous()
+        N = frames.shape[0]
+        out = torch.empty(N, self.cfg.hidden, device=self.device, dtype=self.dtype)
+        step = self.chunk if self.chunk and self.chunk < N else N
+        ws = self.ws.get(lib.avllm_clip_workspace_bytes(C.byref(self.desc), step))
+        for s in range(0, N, step):
+            n = min(step, N - s)
+            L.check(lib.avllm_clip_vision_cls_fwd(C.byref(self.desc), L.ptr(frames[s:]), n, L.ptr(out[s:]), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return out
+
+
+LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj")
+
+
+class LlamaEngine:
+    """Llama + LoRA: avllm_llama_lora_fwd_loss / _bwd (training) and prefill / decode_step (generation).
+
+    Trainable state: one flat fp32 buffer `lora_p` holding, per layer, [A_q,B_q,A_k,B_k,A_v,B_v,A_o,B_o]
+    (A [r,d], B [d,r]) so a layer's gradient bucket is one contiguous slice of `lora_g` for the DDP all-reduce.
+    """
+
+    def __init__(self, sd, cfg, lora_cfg=None, lora_sd=None, dtype=torch.bfloat16, device="cuda", training=True):
+        self.cfg, self.lcfg, self.dtype, self.device, self.training = cfg, lora_cfg, dtype, device, training
+        self.keep = []
+        d, f = cfg.hidden, cfg.ffn
+        self.use_lora = lora_cfg is not None
+        r = lora_cfg.r if self.use_lora else 0
+        self.r = r
+        m = L.Llama()
+        m.dtype, m.d, m.heads, m.layers, m.ffn, m.vocab, m.lora_r = (
+            L.F32 if dtype == torch.float32 else L.BF16, d, cfg.heads, cfg.layers, f, cfg.vocab, r)
+        m.eps, m.theta, m.lora_scale = cfg.eps, cfg.theta, (lora_cfg.scale if self.use_lora else 0.0)
+
+        def put(val):
+            dv = _dev(val, dtype, device)
+            self.keep.append(dv)
+            return dv
+
+        self.embed = put(sd["model.embed_tokens.weight"])
+        m.embed = self.embed.data_ptr()
+        m.norm_w = put(sd["model.norm.weight"]).data_ptr()
+        head = put(sd["lm_head.weight"])
+        m.lm_head = head.data_ptr()
+        if training:
+            m.lm_head_t = put(head.t()).data_ptr()
+        self.layers = (L.LlamaLayer * cfg.layers)()
+        # ---- LoRA masters / grads / padded operand images
+        self.per_layer = 8 * r * d
+        n = cfg.layers * self.per_layer
+        if self.use_lora:
+            self.lora_p = torch.zeros(n, dtype=torch.float32, device=device)
+            self.lora_g = torch.zeros(n, dtype=torch.float32, device=device)
+            P = L.LORA_PAD
+            self.img_A = torch.zeros(cfg.layers, 4, P, d, dtype=dtype, device=device)
+            self.img_ATqkv = torch.zeros(cfg.layers, d, 3 * P, dtype=dtype, device=device)
+            self.img_ATo = torch.zeros(cfg.layers, d, P, dtype=dtype, device=device)
+            self.img_B = torch.zeros(cfg.layers, 4, d, P, dtype=dtype, device=device)
+            self.img_BT = torch.zeros(cfg.layers, 4, P, d, dtype=dtype, device=device)
+            if lora_sd is not None:
+                self.load_lora(lora_sd)
+        for i in range(cfg.layers):
+            p = f"model.layers.{i}."
+            ly = self.layers[i]
+            wqkv = put(torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"],
+                                  sd[p + "self_attn.v_proj.weight"]], 0))
+            wo = put(sd[p + "self_attn.o_proj.weight"])
+            wgu = put(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0))
+            wdown = put(sd[p + "mlp.down_proj.weight"])
+            ly.ln1_w = put(sd[p + "input_layernorm.weight"]).data_ptr()
+            ly.ln2_w = put(sd[p + "post_attention_layernorm.weight"]).data_ptr()
+            ly.wqkv, ly.wo, ly.wgu, ly.wdown = wqkv.data_ptr(), wo.data_ptr(), wgu.data_ptr(), wdown.data_ptr()
+            if training:
+                ly.wqkv_t, ly.wo_t = put(wqkv.t()).data_ptr(), put(wo.t()).data_ptr()
+                ly.wgu_t, ly.wdown_t = put(wgu.t()).data_ptr(), put(wdown.t()).data_ptr()
+            if self.use_lora:
+                es = self.img_A.element_size()
+                for j in range(4):
+                    lm = ly.lora[j]
+                    lm.A_pad = self.img_A[i, j].data_ptr()
+                    lm.B_pad = self.img_B[i, j].data_ptr()
+                    lm.BT_pad = self.img_BT[i, j].data_ptr()
+                    if j < 3:
+                        lm.AT_pad, lm.ld_at = self.img_ATqkv[i].data_ptr() + j * L.LORA_PAD * es, 3 * L.LORA_PAD
+                    else:
+                        lm.AT_pad, lm.ld_at = self.img_ATo[i].data_ptr(), L.LORA_PAD
+                    a, b = self._slices(i, j)
+                    lm.gA = self.lora_g[a[0]:a[1]].data_ptr()
+                    lm.gB = self.lora_g[b[0]:b[1]].data_ptr()
+        m.layer = C.cast(self.layers, C.POINTER(L.LlamaLayer))
+        self.desc = m
+        self.ws = Workspace(device)
+        self.acc = torch.zeros(2, dtype=torch.float32, device=device)     # [loss_sum, count]
+        if self.use_lora:
+            self.pack_lora()
+
+    # flat-buffer offsets of module j (0..3 = q,k,v,o) in layer i: (A range, B range)
+    def _slices(self, i, j):
+        r, d = self.r, self.cfg.hidden
+        base = i * self.per_layer + j * 2 * r * d
+        return (base, base + r * d), (base + r * d, base + 2 * r * d)
+
+    def lora_views(self, buf=None):
+        """dict key -> fp32 view into the flat buffer, keys `layers.{i}.{module}.lora_A|B` (oracle naming)."""
+        buf = self.lora_p if buf is None else buf
+        r, d = self.r, self.cfg.hidden
+        out = {}
+        for i in range(self.cfg.layers):
+            for j, nm in enumerate(LORA_TARGETS):
+                a, b = self._slices(i, j)
+                out[f"layers.{i}.{nm}.lora_A"] = buf[a[0]:a[1]].view(r, d)
+                out[f"layers.{i}.{nm}.lora_B"] = buf[b[0]:b[1]].view(d, r)
+        return out
+
+    def load_lora(self, lora_sd):
+        v = self.lora_views()
+        for k, t in lora_sd.items():
+            v[k].copy_(t.to(device=self.device, dtype=torch.float32))
+
+    def pack_lora(self):
+        """Refresh the padded operand images from the fp32 masters (after every optimizer step)."""
+        lib = L.load()
+        r, d = self.r, self.cfg.hidden
+        st = L.stream_ptr()
+        dt = self.desc.dtype
+        for i in range(self.cfg.layers):
+            for j in range(4):
+                a, b = self._slices(i, j)
+                lm = self.layers[i].lora[j]
+                L.check(lib.avllm_lora_pack(self.lora_p[a[0]:a[1]].data_ptr(), self.lora_p[b[0]:b[1]].data_ptr(), r, d, d,
+                                            lm.A_pad, lm.AT_pad, lm.ld_at, lm.B_pad, lm.BT_pad, dt, st))
+
+    # ------------------------------------------------------------------ training
+    def fwd_loss(self, x, labels, want_logits=False):
+        """x [B,S,d] (engine dtype), labels int64 [B,S] (-100 applied).  Leaves loss_sum,count in self.acc."""
+        lib = L.load()
+        B, S, _ = x.shape
+        x = x.contiguous()
+        labels = labels.contiguous()
+        ws = self.ws.get(lib.avllm_llama_train_workspace_bytes(C.byref(self.desc), B, S))
+        logits = torch.empty(B, S, self.cfg.vocab, device=self.device, dtype=self.dtype) if want_logits else None
+        self.acc.zero_()
+        L.check(lib.avllm_llama_lora_fwd_loss(C.byref(self.desc), L.ptr(x), L.ptr(labels), B, S, L.ptr(logits), L.ptr(self.acc),
+                                              L.ptr(self.acc) + 4, L.ptr(ws), ws.numel(), L.stream_ptr()))
+        self._last = (B, S, labels)
+        return logits
+
+    def bwd(self, grad_scale=1.0, count=None, after_layer=None):
+        """Accumulates LoRA grads into self.lora_g (zero it first).  `count` = device float tensor holding the
+        (possibly all-reduced) number of scored tokens; defaults to this rank's."""
+        lib = L.load()
+        B, S, labels = self._last
+        ws = self.ws.get(lib.avllm_llama_train_workspace_bytes(C.byref(self.desc), B, S))
+        cnt = self.acc[1:2] if count is None else count
+        cb = L.LAYER_CB(lambda l, u: after_layer(l)) if after_layer is not None else L.LAYER_CB(0)
+        L.check(lib.avllm_llama_lora_bwd(C.byref(self.desc), L.ptr(labels), B, S, L.ptr(cnt), grad_scale, L.ptr(ws), ws.numel(),
+                                         cb, None, L.stream_ptr()))
+
+    # ------------------------------------------------------------------ inference
+    def alloc_cache(self, B, Tmax):
+        shape = (self.cfg.layers, B, Tmax, self.cfg.hidden)
+        return torch.empty(shape, dtype=self.dtype, device=self.device), torch.empty(shape, dtype=self.dtype, device=self.device)
+
+    def prefill(self, x, kc, vc, all_logits=False):
+        lib = L.load()
+        B, S, _ = x.shape
+        x = x.contiguous()
+        Tmax = kc.shape[2]
+        ws = self.ws.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, S))
+        last = torch.empty(B, self.cfg.vocab, device=self.device, dtype=torch.float32)
+        full = torch.empty(B, S, self.cfg.vocab, device=self.device, dtype=self.dtype) if all_logits else None
+        L.check(lib.avllm_llama_prefill(C.byref(self.desc), L.ptr(x), B, S, L.ptr(kc), L.ptr(vc), Tmax, L.ptr(last), L.ptr(full),
+                                        L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return last, full
+
+    def decode_step(self, ids, pos, kc, vc):
+        lib = L.load()
+        B = ids.shape[0]
+        ws = self.ws.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, 1))
+        logits = torch.empty(B, self.cfg.vocab, device=self.device, dtype=torch.float32)
+        L.check(lib.avllm_llama_decode_step(C.byref(self.desc), L.ptr(ids.contiguous()), B, pos, L.ptr(kc), L.ptr(vc), kc.shape[2],
+                                            L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return logits

@@ -1,0 +1,201 @@
+"""Tensor-level wrappers over the op-level C ABI (include/avllm.h).  Tensors only carry pointers/strides;
+all arithmetic happens in libavllm.so on the current torch stream."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _ld(t):
+    assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, alpha=1.0, out_f32=False,
+         r_mod=0, remap=None, M=None):
+    """out[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias) + R.  A [M,K] (row stride free), B [N,K]."""
+    lib = L.load()
+    M = A.shape[0] if M is None else M
+    N, K = B.shape[0], B.shape[1]
+    dt = L.dt_of(A)
+    if out is None:
+        rows = M if remap is None else (M // remap[0]) * remap[1]
+        out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if (out_f32 or dt == L.F32) else A.dtype)
+    d = L.GemmDesc()
+    d.A, d.B, d.C = L.ptr(A), L.ptr(B), L.ptr(out)
+    d.lda, d.ldb, d.ldc = _ld(A), _ld(B), _ld(out)
+    d.M, d.N, d.K = M, N, K
+    if A2 is not None:
+        d.A2, d.B2, d.lda2, d.ldb2, d.K2 = L.ptr(A2), L.ptr(B2), _ld(A2), _ld(B2), B2.shape[1]
+    d.bias = L.ptr(bias)
+    if R is not None:
+        d.R, d.ldr = L.ptr(R), _ld(R)
+    d.dtype, d.out_f32, d.act, d.alpha, d.r_mod = dt, int(out_f32), act, alpha, r_mod
+    if remap is not None:
+        d.g_in, d.g_out, d.g_off = remap
+    L.check(lib.avllm_gemm(C.byref(d), L.stream_ptr()))
+    return out
+
+
+def gemm_tn(P, Q, out, I=None, J=None, alpha=1.0):
+    lib = L.load()
+    I = P.shape[1] if I is None else I
+    J = Q.shape[1] if J is None else J
+    L.check(lib.avllm_gemm_tn(L.ptr(P), _ld(P), I, L.ptr(Q), _ld(Q), J, P.shape[0], L.ptr(out), _ld(out), alpha,
+                              L.dt_of(P), L.stream_ptr()))
+    return out
+
+
+def layernorm(x, w, b, eps=1e-5):
+    y = torch.empty_like(x)
+    L.check(L.load().avllm_layernorm(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), x.numel() // x.shape[-1], x.shape[-1], eps,
+                                     L.dt_of(x), L.stream_ptr()))
+    return y
+
+
+def rmsnorm_fwd(x, w, eps):
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L.check(L.load().avllm_rmsnorm_fwd(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(rstd), rows, x.shape[-1], eps, L.dt_of(x), L.stream_ptr()))
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None):
+    dx = torch.empty_like(x)
+    L.check(L.load().avllm_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
+                                       x.numel() // x.shape[-1], x.shape[-1], L.dt_of(x), L.stream_ptr()))
+    return dx
+
+
+def rope_(x2d, T, heads, hd, pos0=0, theta=10000.0, inverse=False):
+    """In place on a [rows, heads*hd] view (row stride free)."""
+    L.check(L.load().avllm_rope(L.ptr(x2d), _ld(x2d), x2d.shape[0], T, heads, hd, pos0, theta, int(inverse), L.dt_of(x2d), L.stream_ptr()))
+    return x2d
+
+
+def swiglu_fwd(gu):
+    M, F2 = gu.shape
+    h = torch.empty(M, F2 // 2, device=gu.device, dtype=gu.dtype)
+    L.check(L.load().avllm_swiglu_fwd(L.ptr(gu), L.ptr(h), M, F2 // 2, L.dt_of(gu), L.stream_ptr()))
+    return h
+
+
+def swiglu_bwd(dh, gu):
+    dgu = torch.empty_like(gu)
+    L.check(L.load().avllm_swiglu_bwd(L.ptr(dh), L.ptr(gu), L.ptr(dgu), gu.shape[0], gu.shape[1] // 2, L.dt_of(gu), L.stream_ptr()))
+    return dgu
+
+
+def attention_fwd(qkv, B, T, H, hd, causal, scale=None, impl=0, want_lse=True):
+    """qkv [B*T, 3*H*hd] fused rows -> (o [B*T, H*hd], lse [B,H,T])."""
+    d = H * hd
+    o = torch.empty(B * T, d, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32) if want_lse else None
+    es = qkv.element_size()
+    scale = hd ** -0.5 if scale is None else scale
+    p = L.ptr(qkv)
+    L.check(L.load().avllm_attention_fwd(p, p + d * es, p + 2 * d * es, L.ptr(o), L.ptr(lse), B, T, T, H, hd, _ld(qkv), _ld(qkv),
+                                         _ld(qkv), d, scale, int(causal), L.dt_of(qkv), impl, L.stream_ptr()))
+    return o, lse
+
+
+def attention_bwd(qkv, o, dout, lse, B, T, H, hd, causal, scale=None, impl=0):
+    d = H * hd
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+    es = qkv.element_size()
+    scale = hd ** -0.5 if scale is None else scale
+    p, g = L.ptr(qkv), L.ptr(dqkv)
+    L.check(L.load().avllm_attention_bwd(p, p + d * es, p + 2 * d * es, L.ptr(o), L.ptr(dout), L.ptr(lse), g, g + d * es, g + 2 * d * es,
+                                         L.ptr(delta), B, T, H, hd, _ld(qkv), _ld(qkv), _ld(qkv), d, _ld(dqkv), _ld(dqkv), _ld(dqkv),
+                                         scale, int(causal), L.dt_of(qkv), impl, L.stream_ptr()))
+    return dqkv
+
+
+def ce_fwd(logits, labels):
+    """logits [B,T,V], labels int64 [B,T] (-100 = ignore) -> (row_lse [B*T], loss_sum [1], count [1])."""
+    B, T, V = logits.shape
+    row_lse = torch.empty(B * T, device=logits.device, dtype=torch.float32)
+    acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    L.check(L.load().avllm_ce_fwd(L.ptr(logits), logits.stride(1), L.ptr(labels), B, T, V, L.ptr(row_lse), L.ptr(acc), L.ptr(acc) + 4,
+                                  L.dt_of(logits), L.stream_ptr()))
+    return row_lse, acc
+
+
+def ce_bwd(logits, labels, row_lse, acc, grad_scale=1.0):
+    B, T, V = logits.shape
+    dl = torch.empty_like(logits)
+    L.check(L.load().avllm_ce_bwd(L.ptr(logits), logits.stride(1), L.ptr(labels), L.ptr(row_lse), L.ptr(acc) + 4, grad_scale, L.ptr(dl),
+                                  B, T, V, L.dt_of(logits), L.stream_ptr()))
+    return dl
+
+
+def argmax_rows(logits2d):
+    out = torch.empty(logits2d.shape[0], device=logits2d.device, dtype=torch.int64)
+    L.check(L.load().avllm_argmax_rows(L.ptr(logits2d), _ld(logits2d), logits2d.shape[0], logits2d.shape[1], L.ptr(out),
+                                       L.dt_of(logits2d), L.stream_ptr()))
+    return out
+
+
+def embedding(table, ids):
+    ids = ids.contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], device=table.device, dtype=table.dtype)
+    L.check(L.load().avllm_embedding(L.ptr(table), L.ptr(ids), L.ptr(out), ids.numel(), table.shape[1], L.dt_of(table), L.stream_ptr()))
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty_like(x, dtype=dtype)
+    if x.numel():
+        L.check(L.load().avllm_cast(L.ptr(x), L.dt_of(x), L.ptr(out), L.dt_of(out), x.numel(), L.stream_ptr()))
+    return out
+
+
+def fuse_pool(a, v, prompt_emb, L_, S_out, fusion_scale, D, B):
+    """See avllm_fuse_pool in include/avllm.h.  a [B,Ta,D] | None, v [B,Tv,D] | None, prompt_emb [B,P,D] | None."""
+    ref = a if a is not None else v
+    out = torch.empty(B, S_out, D, device=ref.device, dtype=ref.dtype)
+    Ta = a.shape[1] if a is not None else 0
+    Tv = v.shape[1] if v is not None else 0
+    P = prompt_emb.shape[1] if prompt_emb is not None else 0
+    L.check(L.load().avllm_fuse_pool(L.ptr(a), Ta, L.ptr(v), Tv, L.ptr(prompt_emb), P, L.ptr(out), B, L_, S_out, D, fusion_scale,
+                                     L.dt_of(ref), L.stream_ptr()))
+    return out
+
+
+def grad_sumsq(g, out):
+    L.check(L.load().avllm_grad_sumsq(L.ptr(g), g.numel(), L.ptr(out), L.stream_ptr()))
+
+
+def adamw_step(p, g, m, v, lr, step, sumsq=None, max_norm=0.0, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.01, prescale=1.0):
+    L.check(L.load().avllm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+                                      L.ptr(sumsq), max_norm, prescale, L.stream_ptr()))
+
+
+def whisper_im2col1(mel, Kpad, dtype):
+    B, n_mels, T = mel.shape
+    cols = torch.empty(B * T, Kpad, device=mel.device, dtype=dtype)
+    L.check(L.load().avllm_whisper_im2col1(L.ptr(mel), L.ptr(cols), B, n_mels, T, Kpad, L.dt_of(cols), L.stream_ptr()))
+    return cols
+
+
+def whisper_im2col2(h, B, T):
+    d = h.shape[-1]
+    cols = torch.empty(B * (T // 2), 3 * d, device=h.device, dtype=h.dtype)
+    L.check(L.load().avllm_whisper_im2col2(L.ptr(h), L.ptr(cols), B, T, d, L.dt_of(h), L.stream_ptr()))
+    return cols
+
+
+def clip_patchify(frames, patch, Kpad, dtype):
+    N, _, S, _ = frames.shape
+    g = S // patch
+    cols = torch.empty(N * g * g, Kpad, device=frames.device, dtype=dtype)
+    L.check(L.load().avllm_clip_patchify(L.ptr(frames), L.ptr(cols), N, S, patch, Kpad, L.dt_of(cols), L.stream_ptr()))
+    return cols

@@ -1,0 +1,211 @@
+// Flash attention forward for gfx950 (bf16 in, fp32 softmax/accumulate), head_dim 64 (Whisper / CLIP
+// encoders, non-causal) and 128 (Llama, causal).  HF eager_attention_forward restated as a single pass:
+// whisper :215-238, clip :259-277 (fp32 softmax), llama sdpa path.
+//
+// Layout choices (CDNA4): one wave owns 32 query rows; the workgroup (NW waves) shares K/V tiles of 64 keys
+// staged in LDS.  Scores are computed TRANSPOSED, S^T = K.Q^T, with v_mfma_f32_32x32x16_bf16: the query
+// index then lives on the lane, so the online-softmax running max / sum / rescale are lane-local scalars and
+// the row reduction is 15 in-register max/adds + one cross-half shuffle.  The S^T accumulator registers are,
+// after a pairwise bf16 convert, directly the B operand of O^T += V^T.P^T (cdna guide §3 "An accumulator tile
+// as the next MFMA's operand"), so P never touches LDS.  V^T fragments come from the row-major V tile through
+// ds_read_b64_tr_b16 (hardware transpose).  K rows are padded by 16 B and V rows by 64 B, which makes the
+// ds_read_b128 row reads and the 4-row transposed reads bank-conflict free (MI355X_MICROARCH §LDS).
+#include "common.h"
+#include "avllm_internal.h"
+
+int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
+                         int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st);
+int av_attention_delta(const void* o, const void* dout, float* delta, int B, int T, int H, int hd, long ldo, long lddo, int dtype, hipStream_t st);
+int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                         void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
+                         long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st);
+int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                          void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st);
+
+namespace {
+
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <int HD, int NW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                         const bf16* __restrict__ v, bf16* __restrict__ o, float* __restrict__ lse,
+                                                         int Tq, int Tk, int H, long ldq, long ldk, long ldv, long ldo,
+                                                         float scale_log2e) {
+    constexpr int KS = HD * 2 + 16;      // K tile row stride (bytes)
+    constexpr int VS = HD * 2 + 64;      // V tile row stride (bytes)
+    constexpr int CPR = HD / 8;          // 16-byte chunks per row
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char k_lds[64 * KS];
+    __shared__ __attribute__((aligned(16))) char v_lds[64 * VS];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int hh = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + w) * 32;
+    const int off = Tk - Tq;                                   // causal: query t sees keys <= t + off
+    const int qpos = q0 + r;
+    const int qrow = qpos < Tq ? qpos : Tq - 1;
+
+    // Q fragments: B operand of S^T = K.Q^T  -> lane holds Q[query r][16ks + 8half .. +8]
+    bf16x8 qf[HD / 16];
+    {
+        const bf16* qp = q + ((long)b * Tq + qrow) * ldq + (long)hh * HD + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+    }
+    f32x16 oacc[HD / 32];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int blk_qmax = min(Tq - 1, (int)(blockIdx.x * NW + NW) * 32 - 1);
+    const int k_end = CAUSAL ? min(Tk, blk_qmax + off + 1) : Tk;      // keys [0,k_end) are needed by this block
+    const bool wave_active = q0 < Tq;
+    const int wave_kmax = CAUSAL ? min(Tk - 1, min(Tq - 1, q0 + 31) + off) : Tk - 1;
+
+    for (int kb = 0; kb < k_end; kb += 64) {
+        __syncthreads();                       // previous tile fully consumed
+        for (int c = tid; c < 64 * CPR; c += NT) {
+            const int row = c / CPR, ch = c % CPR;
+            const int key = kb + row;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (key < Tk) {
+                kv = *(const u32x4*)(k + ((long)b * Tk + key) * ldk + (long)hh * HD + ch * 8);
+                vv = *(const u32x4*)(v + ((long)b * Tk + key) * ldv + (long)hh * HD + ch * 8);
+            }
+            *(u32x4*)(k_lds + row * KS + ch * 16) = kv;
+            *(u32x4*)(v_lds + row * VS + ch * 16) = vv;
+        }
+        __syncthreads();
+        if (!wave_active || kb > wave_kmax) continue;      // wave-uniform
+
+        const bool two = (kb + 32 <= wave_kmax) && (kb + 32 < Tk);   // second 32-key sub-block has visible keys
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            const bf16x8 kf0 = *(const bf16x8*)(k_lds + r * KS + (2 * ks + half) * 16);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
+        }
+        if (two) {
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) {
+                const bf16x8 kf1 = *(const bf16x8*)(k_lds + (32 + r) * KS + (2 * ks + half) * 16);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+            }
+        }
+        // mask + block max
+        const int klim = CAUSAL ? min(Tk - 1, qpos + off) : Tk - 1;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key0 = kb + acc_row(i, half);
+            s0[i] = key0 <= klim ? s0[i] * scale_log2e : -INFINITY;
+            s1[i] = (two && key0 + 32 <= klim) ? s1[i] * scale_log2e : -INFINITY;
+            mloc = fmaxf(mloc, fmaxf(s0[i], s1[i]));
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = exp2f(s0[i] - m_use);
+            s1[i] = exp2f(s1[i] - m_use);
+            psum += s0[i] + s1[i];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+
+        // O^T += V^T . P^T   (k = keys; 2 k-steps of 16 per 32-key sub-block)
+        const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            if (sb == 1 && !two) break;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (bf16)(sb == 0 ? s0[8 * s + j] : s1[8 * s + j]);
+                const int krow = 32 * sb + 16 * s + 4 * half + (i16 >> 2);
+#pragma unroll
+                for (int d = 0; d < HD / 32; ++d) {
+                    const int col = 32 * d + 16 * (g & 1) + 4 * (i16 & 3);
+                    const char* a0 = v_lds + krow * VS + col * 2;
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(a0));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(a0 + 8 * VS));
+                    typedef __attribute__((ext_vector_type(8))) short short8v;
+                    const short8v both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 vt = __builtin_bit_cast(bf16x8, both);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pb, oacc[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qpos < Tq) {
+        bf16* op = o + ((long)b * Tq + qpos) * ldo + (long)hh * HD;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float vals[4] = {oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv, oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv};
+                store_f<4>(op + 32 * d + 8 * g4 + 4 * half, vals);
+            }
+        if (lse && half == 0) lse[((long)b * H + hh) * Tq + qpos] = (m_run + log2f(l_tot)) * 0.69314718055994531f;
+    }
+}
+
+template <int HD, int NW>
+int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H, long ldq,
+               long ldk, long ldv, long ldo, float scale, int causal, hipStream_t st) {
+    const dim3 grid(av_cdiv(Tq, 32 * NW), H, B), block(NW * 64);
+    const float sl = scale * 1.4426950408889634f;
+    if (causal) hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl);
+    else hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // namespace
+
+int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
+                     int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, int impl,
+                     hipStream_t st) {
+    AV_CHECK_ARG(q && k && v && o && B > 0 && Tq > 0 && Tk > 0 && H > 0, "attention_fwd: bad args");
+    AV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "attention_fwd: row strides must be multiples of 8");
+    AV_CHECK_ARG(!causal || Tk >= Tq, "attention_fwd: causal needs Tk >= Tq");
+    if (impl == 1 || dtype == AV_F32 || (hd != 64 && hd != 128))
+        return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st);
+    if (hd == 64) {
+        // short sequences (CLIP: 197 tokens): one workgroup covers the whole sequence with 7 waves
+        if (Tq <= 224 && Tq > 128) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
+        return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
+    }
+    return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
+}
+
+int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                     void* dq, void* dk, void* dv, float* delta_ws, int B, int T, int H, int hd, long ldq, long ldk,
+                     long ldv, long ldo, long lddq, long lddk, long lddv, float scale, int causal, int dtype, int impl,
+                     hipStream_t st) {
+    AV_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta_ws, "attention_bwd: null");
+    // dO shares O's row stride
+    AV_TRY(av_attention_delta(o, dout, delta_ws, B, T, H, hd, ldo, ldo, dtype, st));
+    if (impl == 0 && dtype == AV_BF16 && hd == 128)
+        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st);
+    return av_attention_bwd_ref(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, st);
+}

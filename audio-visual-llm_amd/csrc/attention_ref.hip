@@ -1,0 +1,255 @@
+// Scalar (one wave per row) softmax attention, forward and backward, any dtype / head_dim <= 128.
+// This is the strict-parity (fp32) implementation and the in-library cross-check for the MFMA kernels
+// (impl=1 in avllm_attention_fwd/bwd); it is NOT the bf16 hot path.  Also: delta = rowsum(dO*O) and the
+// single-token KV-cache attention used by greedy decode (HBM-bound: K/V rows streamed once, 16-B loads).
+// Reference arithmetic: HF eager_attention_forward (softmax(QK^T*scale+mask)V), autograd for the backward.
+#include "common.h"
+#include "avllm_internal.h"
+
+namespace {
+
+constexpr int MAXHD = 128;
+
+template <typename T>
+__device__ __forceinline__ float dot_row(const float* __restrict__ qs, const T* __restrict__ kr, int hd) {
+    float s = 0.f;
+    for (int c = 0; c < hd; c += 8) {
+        float kv[8];
+        load_f<8>(kr + c, kv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += qs[c + j] * kv[j];
+    }
+    return s;
+}
+
+// grid (ceil(Tq/4), H, B); wave w -> query t
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                    T* __restrict__ o, float* __restrict__ lse, int Tq, int Tk, int H, int hd,
+                                                    long ldq, long ldk, long ldv, long ldo, float scale, int causal) {
+    __shared__ float qs[4][MAXHD];
+    __shared__ float ps[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    if (t >= Tq) return;
+    const T* qr = q + ((long)b * Tq + t) * ldq + (long)h * hd;
+    for (int c = lane; c < hd; c += 64) qs[w][c] = to_f(qr[c]);
+    __builtin_amdgcn_wave_barrier();
+    const int limit = causal ? t + (Tk - Tq) : Tk - 1;      // last visible key
+    float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int kb = 0; kb <= limit && kb < Tk; kb += 64) {
+        const int j = kb + lane;
+        const bool valid = j < Tk && j <= limit;
+        float s = -INFINITY;
+        if (valid) s = scale * dot_row(qs[w], k + ((long)b * Tk + j) * ldk + (long)h * hd, hd);
+        const float mn = fmaxf(m, wave_max(s));
+        const float p = valid ? __expf(s - mn) : 0.f;
+        const float alpha = __expf(m - mn);
+        l = l * alpha + wave_sum(p);
+        m = mn;
+        __builtin_amdgcn_wave_barrier();
+        ps[w][lane] = p;
+        __builtin_amdgcn_wave_barrier();
+        o0 *= alpha; o1 *= alpha;
+        const int nj = min(64, min(Tk, limit + 1) - kb);
+        for (int jj = 0; jj < nj; ++jj) {
+            const T* vr = v + ((long)b * Tk + kb + jj) * ldv + (long)h * hd;
+            const float pj = ps[w][jj];
+            if (lane < hd) o0 += pj * to_f(vr[lane]);
+            if (lane + 64 < hd) o1 += pj * to_f(vr[lane + 64]);
+        }
+    }
+    T* orow = o + ((long)b * Tq + t) * ldo + (long)h * hd;
+    const float inv = 1.0f / l;
+    if (lane < hd) orow[lane] = from_f<T>(o0 * inv);
+    if (lane + 64 < hd) orow[lane + 64] = from_f<T>(o1 * inv);
+    if (lse && lane == 0) lse[((long)b * H + h) * Tq + t] = m + logf(l);
+}
+
+// delta[b,h,t] = sum_d dO*O ; grid (ceil(T/4), H, B)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta,
+                                                         int Tn, int H, int hd, long ldo, long lddo) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    if (t >= Tn) return;
+    const T* orow = o + ((long)b * Tn + t) * ldo + (long)h * hd;
+    const T* drow = dout + ((long)b * Tn + t) * lddo + (long)h * hd;
+    float s = 0.f;
+    for (int c = lane; c < hd; c += 64) s += to_f(orow[c]) * to_f(drow[c]);
+    s = wave_sum(s);
+    if (lane == 0) delta[((long)b * H + h) * Tn + t] = s;
+}
+
+// dQ: wave per query
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_ref(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                       const T* __restrict__ dout, const float* __restrict__ lse,
+                                                       const float* __restrict__ delta, T* __restrict__ dq, int Tn, int H, int hd,
+                                                       long ldq, long ldk, long ldv, long lddo, long lddq, float scale, int causal) {
+    __shared__ float qs[4][MAXHD], dos[4][MAXHD];
+    __shared__ float dss[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    if (t >= Tn) return;
+    const T* qr = q + ((long)b * Tn + t) * ldq + (long)h * hd;
+    const T* dr = dout + ((long)b * Tn + t) * lddo + (long)h * hd;
+    for (int c = lane; c < hd; c += 64) { qs[w][c] = to_f(qr[c]); dos[w][c] = to_f(dr[c]); }
+    __builtin_amdgcn_wave_barrier();
+    const float L = lse[((long)b * H + h) * Tn + t], D = delta[((long)b * H + h) * Tn + t];
+    const int limit = causal ? t : Tn - 1;
+    float g0 = 0.f, g1 = 0.f;
+    for (int kb = 0; kb <= limit; kb += 64) {
+        const int j = kb + lane;
+        const bool valid = j <= limit;
+        float ds = 0.f;
+        if (valid) {
+            const float s = scale * dot_row(qs[w], k + ((long)b * Tn + j) * ldk + (long)h * hd, hd);
+            const float p = __expf(s - L);
+            const float dp = dot_row(dos[w], v + ((long)b * Tn + j) * ldv + (long)h * hd, hd);
+            ds = p * (dp - D) * scale;
+        }
+        __builtin_amdgcn_wave_barrier();
+        dss[w][lane] = ds;
+        __builtin_amdgcn_wave_barrier();
+        const int nj = min(64, limit + 1 - kb);
+        for (int jj = 0; jj < nj; ++jj) {
+            const T* kr = k + ((long)b * Tn + kb + jj) * ldk + (long)h * hd;
+            const float d = dss[w][jj];
+            if (lane < hd) g0 += d * to_f(kr[lane]);
+            if (lane + 64 < hd) g1 += d * to_f(kr[lane + 64]);
+        }
+    }
+    T* out = dq + ((long)b * Tn + t) * lddq + (long)h * hd;
+    if (lane < hd) out[lane] = from_f<T>(g0);
+    if (lane + 64 < hd) out[lane + 64] = from_f<T>(g1);
+}
+
+// dK,dV: wave per key
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_ref(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        const T* __restrict__ dout, const float* __restrict__ lse,
+                                                        const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv, int Tn,
+                                                        int H, int hd, long ldq, long ldk, long ldv, long lddo, long lddk, long lddv,
+                                                        float scale, int causal) {
+    __shared__ float ks[4][MAXHD], vs[4][MAXHD];
+    __shared__ float ps[4][64], dss[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+    if (j >= Tn) return;
+    const T* kr = k + ((long)b * Tn + j) * ldk + (long)h * hd;
+    const T* vr = v + ((long)b * Tn + j) * ldv + (long)h * hd;
+    for (int c = lane; c < hd; c += 64) { ks[w][c] = to_f(kr[c]); vs[w][c] = to_f(vr[c]); }
+    __builtin_amdgcn_wave_barrier();
+    const int first = causal ? j : 0;
+    float gk0 = 0.f, gk1 = 0.f, gv0 = 0.f, gv1 = 0.f;
+    for (int qb = (first / 64) * 64; qb < Tn; qb += 64) {
+        const int i = qb + lane;
+        const bool valid = i < Tn && i >= first;
+        float p = 0.f, ds = 0.f;
+        if (valid) {
+            const float s = scale * dot_row(ks[w], q + ((long)b * Tn + i) * ldq + (long)h * hd, hd);
+            p = __expf(s - lse[((long)b * H + h) * Tn + i]);
+            const float dp = dot_row(vs[w], dout + ((long)b * Tn + i) * lddo + (long)h * hd, hd);
+            ds = p * (dp - delta[((long)b * H + h) * Tn + i]) * scale;
+        }
+        __builtin_amdgcn_wave_barrier();
+        ps[w][lane] = p; dss[w][lane] = ds;
+        __builtin_amdgcn_wave_barrier();
+        const int ni = min(64, Tn - qb);
+        for (int ii = 0; ii < ni; ++ii) {
+            const T* qr = q + ((long)b * Tn + qb + ii) * ldq + (long)h * hd;
+            const T* dr = dout + ((long)b * Tn + qb + ii) * lddo + (long)h * hd;
+            const float pp = ps[w][ii], dd = dss[w][ii];
+            if (lane < hd) { gv0 += pp * to_f(dr[lane]); gk0 += dd * to_f(qr[lane]); }
+            if (lane + 64 < hd) { gv1 += pp * to_f(dr[lane + 64]); gk1 += dd * to_f(qr[lane + 64]); }
+        }
+    }
+    T* ok = dk + ((long)b * Tn + j) * lddk + (long)h * hd;
+    T* ov = dv + ((long)b * Tn + j) * lddv + (long)h * hd;
+    if (lane < hd) { ok[lane] = from_f<T>(gk0); ov[lane] = from_f<T>(gv0); }
+    if (lane + 64 < hd) { ok[lane + 64] = from_f<T>(gk1); ov[lane + 64] = from_f<T>(gv1); }
+}
+
+// single-token attention over a KV cache [B,Tmax,d]: block per (b,h), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, T* __restrict__ o, long ldo, int H, int hd, int Tk,
+                                                          int Tmax, float scale) {
+    extern __shared__ float sh[];            // [hd] q  + [Tk] scores + 8 reduction + [4][hd] partial
+    float* qs = sh; float* sc = sh + hd; float* red = sc + Tk; float* part = red + 8;
+    const int h = blockIdx.x, b = blockIdx.y, d = H * hd;
+    for (int c = threadIdx.x; c < hd; c += 256) qs[c] = to_f(q[(long)b * ldq + (long)h * hd + c]);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < Tk; j += 256) {
+        const float s = scale * dot_row(qs, kc + ((long)b * Tmax + j) * d + (long)h * hd, hd);
+        sc[j] = s; mx = fmaxf(mx, s);
+    }
+    mx = block_max(mx, red);
+    float sm = 0.f;
+    for (int j = threadIdx.x; j < Tk; j += 256) { const float p = __expf(sc[j] - mx); sc[j] = p; sm += p; }
+    sm = block_sum(sm, red);
+    // 256 threads = up to 4 key-groups x 64.. hd columns
+    const int groups = 256 / hd > 0 ? 256 / hd : 1;
+    const int gi = threadIdx.x / hd, c = threadIdx.x % hd;
+    float acc = 0.f;
+    if (gi < groups)
+        for (int j = gi; j < Tk; j += groups) acc += sc[j] * to_f(vc[((long)b * Tmax + j) * d + (long)h * hd + c]);
+    if (gi < groups) part[gi * hd + c] = acc;
+    __syncthreads();
+    if (threadIdx.x < hd) {
+        float t = 0.f;
+        for (int g = 0; g < groups; ++g) t += part[g * hd + threadIdx.x];
+        o[(long)b * ldo + (long)h * hd + threadIdx.x] = from_f<T>(t / sm);
+    }
+}
+
+}  // namespace
+
+int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
+                         int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st) {
+    AV_CHECK_ARG(hd % 8 == 0 && hd <= MAXHD, "attention(ref): head_dim %d unsupported", hd);
+    const dim3 grid(av_cdiv(Tq, 4), H, B);
+    if (dtype == AV_F32) hipLaunchKernelGGL((attn_fwd_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal);
+    else hipLaunchKernelGGL((attn_fwd_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_attention_delta(const void* o, const void* dout, float* delta, int B, int T, int H, int hd, long ldo, long lddo, int dtype, hipStream_t st) {
+    const dim3 grid(av_cdiv(T, 4), H, B);
+    if (dtype == AV_F32) hipLaunchKernelGGL((attn_delta_kernel<float>), grid, dim3(256), 0, st, (const float*)o, (const float*)dout, delta, T, H, hd, ldo, lddo);
+    else hipLaunchKernelGGL((attn_delta_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta, T, H, hd, ldo, lddo);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                         void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
+                         long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st) {
+    AV_CHECK_ARG(hd % 8 == 0 && hd <= MAXHD, "attention_bwd(ref): head_dim %d unsupported", hd);
+    const dim3 grid(av_cdiv(T, 4), H, B);
+    if (dtype == AV_F32) {
+        hipLaunchKernelGGL((attn_bwd_dq_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, delta, (float*)dq, T, H, hd, ldq, ldk, ldv, lddo, lddq, scale, causal);
+        hipLaunchKernelGGL((attn_bwd_dkv_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, delta, (float*)dk, (float*)dv, T, H, hd, ldq, ldk, ldv, lddo, lddk, lddv, scale, causal);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, hd, ldq, ldk, ldv, lddo, lddq, scale, causal);
+        hipLaunchKernelGGL((attn_bwd_dkv_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, hd, ldq, ldk, ldv, lddo, lddk, lddv, scale, causal);
+    }
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
+                        int Tk, int Tmax, float scale, int dtype, hipStream_t st) {
+    AV_CHECK_ARG(q && kc && vc && o && Tk > 0 && Tk <= Tmax, "attention_decode: bad args");
+    AV_CHECK_ARG(hd % 8 == 0 && hd <= 256 && 256 % hd == 0, "attention_decode: head_dim %d unsupported", hd);
+    const size_t sh = (size_t)(hd + Tk + 8 + 4 * hd) * sizeof(float);
+    AV_CHECK_ARG(sh <= 64 * 1024, "attention_decode: Tk=%d too long for the LDS score buffer", Tk);
+    const dim3 grid(H, B);
+    if (dtype == AV_F32) hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), sh, st, (const float*)q, ldq, (const float*)kc, (const float*)vc, (float*)o, ldo, H, hd, Tk, Tmax, scale);
+    else hipLaunchKernelGGL((attn_decode_kernel<bf16>), grid, dim3(256), sh, st, (const bf16*)q, ldq, (const bf16*)kc, (const bf16*)vc, (bf16*)o, ldo, H, hd, Tk, Tmax, scale);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

@@ -1,0 +1,44 @@
+// Internal launchers (typed stream) behind the C ABI of include/avllm.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/avllm.h"
+
+int av_gemm(const avllm_gemm_desc* d, hipStream_t st);
+int av_gemm_tn(const void* P, long ldp, int I, const void* Q, long ldq, int J, int M, float* out, long ldo,
+               float alpha, int dtype, hipStream_t st);
+int av_layernorm(const void* x, const void* w, const void* b, void* y, long rows, int d, float eps, int dtype, hipStream_t st);
+int av_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int d, float eps, int dtype, hipStream_t st);
+int av_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres_in, void* dx_out,
+                   long rows, int d, int dtype, hipStream_t st);
+int av_rope(void* x, long ld, long rows, int T, int heads, int hd, int pos0, float theta, int inverse, int dtype, hipStream_t st);
+int av_swiglu_fwd(const void* gu, void* h, long M, int F, int dtype, hipStream_t st);
+int av_swiglu_bwd(const void* dh, const void* gu, void* dgu, long M, int F, int dtype, hipStream_t st);
+int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
+                     int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, int impl,
+                     hipStream_t st);
+int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                     void* dq, void* dk, void* dv, float* delta_ws, int B, int T, int H, int hd, long ldq, long ldk,
+                     long ldv, long ldo, long lddq, long lddk, long lddv, float scale, int causal, int dtype, int impl,
+                     hipStream_t st);
+int av_ce_fwd(const void* logits, long ld, const int64_t* labels, int B, int T, int V, float* row_lse, float* loss_sum,
+              float* count, int dtype, hipStream_t st);
+int av_ce_bwd(const void* logits, long ld, const int64_t* labels, const float* row_lse, const float* count,
+              float grad_scale, void* dlogits, int B, int T, int V, int dtype, hipStream_t st);
+int av_argmax_rows(const void* logits, long ld, long rows, int V, int64_t* out, int dtype, hipStream_t st);
+int av_embedding(const void* table, const int64_t* ids, void* out, long n, int d, int dtype, hipStream_t st);
+int av_cast(const void* src, int sdt, void* dst, int ddt, long n, hipStream_t st);
+int av_whisper_im2col1(const float* mel, void* cols, int B, int n_mels, int T, int Kpad, int dtype, hipStream_t st);
+int av_whisper_im2col2(const void* h, void* cols, int B, int T, int d, int dtype, hipStream_t st);
+int av_clip_patchify(const float* frames, void* cols, int N, int S, int p, int Kpad, int dtype, hipStream_t st);
+int av_clip_cls_rows(const void* class_emb, const void* pos, void* x, int N, int tokens, int d, int dtype, hipStream_t st);
+int av_fuse_pool(const void* a, int Ta, const void* v, int Tv, const void* prompt_emb, int P, void* out, int B, int L,
+                 int S_out, int D, float fs, int dtype, hipStream_t st);
+int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st);
+int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                  float wd, int step, const float* sumsq, float max_norm, float grad_prescale, hipStream_t st);
+int av_lora_pack(const float* A, const float* Bm, int r, int din, int dout, void* A_pad, void* AT_pad, long ld_at,
+                 void* B_pad, void* BT_pad, int dtype, hipStream_t st);
+int av_kv_append(const void* k, const void* v, long ld, void* kc, void* vc, int B, int T, int pos0, int Tmax, int d,
+                 int dtype, hipStream_t st);
+int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
+                        int Tk, int Tmax, float scale, int dtype, hipStream_t st);

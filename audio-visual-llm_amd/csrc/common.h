@@ -1,0 +1,136 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the AV->LLM hot path.
+// Wavefront = 64 lanes everywhere; no other architecture is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define AV_WAVE 64
+
+// ---- status / error string (thread local), SURVEY.md §8b "Errors" row
+#define AV_OK 0
+#define AV_ERR_ARG 1
+#define AV_ERR_HIP 2
+#define AV_ERR_WORKSPACE 3
+#define AV_ERR_UNSUPPORTED 4
+
+extern "C" const char* avllm_last_error(void);
+int av_set_error(int code, const char* fmt, ...);
+
+#define AV_CHECK_ARG(cond, ...) \
+    do { if (!(cond)) return av_set_error(AV_ERR_ARG, __VA_ARGS__); } while (0)
+#define AV_HIP(expr) \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return av_set_error(AV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define AV_LAUNCH_CHECK() AV_HIP(hipGetLastError())
+#define AV_TRY(expr) do { int rc_ = (expr); if (rc_ != AV_OK) return rc_; } while (0)
+
+enum { AV_F32 = 0, AV_BF16 = 1 };
+enum { AV_ACT_NONE = 0, AV_ACT_GELU = 1, AV_ACT_QUICK_GELU = 2, AV_ACT_SILU = 3 };
+
+static inline size_t av_dtype_size(int dt) { return dt == AV_F32 ? 4 : 2; }
+
+// ---- element helpers ---------------------------------------------------------------------
+template <typename T> struct Vec;   // 16-byte vector of T
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// load/store N consecutive elements (N*sizeof(T) must be 8 or 16 bytes and aligned)
+template <typename T, int N> struct Pack { T v[N]; };
+
+template <int N> __device__ __forceinline__ void load_f(const float* p, float (&o)[N]) {
+    static_assert(N % 4 == 0, "");
+#pragma unroll
+    for (int i = 0; i < N; i += 4) { f32x4 t = *(const f32x4*)(p + i); o[i] = t[0]; o[i + 1] = t[1]; o[i + 2] = t[2]; o[i + 3] = t[3]; }
+}
+template <int N> __device__ __forceinline__ void load_f(const bf16* p, float (&o)[N]) {
+    static_assert(N % 4 == 0, "");
+    if constexpr (N % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) { bf16x8 t = *(const bf16x8*)(p + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[i + j] = (float)t[j]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) { bf16x4 t = *(const bf16x4*)(p + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[i + j] = (float)t[j]; }
+    }
+}
+template <int N> __device__ __forceinline__ void store_f(float* p, const float (&o)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) { f32x4 t = {o[i], o[i + 1], o[i + 2], o[i + 3]}; *(f32x4*)(p + i) = t; }
+}
+template <int N> __device__ __forceinline__ void store_f(bf16* p, const float (&o)[N]) {
+    if constexpr (N % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) { bf16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (bf16)o[i + j];
+            *(bf16x8*)(p + i) = t; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) { bf16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (bf16)o[i + j];
+            *(bf16x4*)(p + i) = t; }
+    }
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// block reduction through LDS; `red` must hold >= blockDim.x/64 floats; all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case AV_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case AV_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case AV_ACT_SILU: return x / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+
+static inline int av_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,484 @@
+// Model-level entry points: the kernel sequences for the Whisper encoder, the CLIP vision tower, and the
+// Llama + LoRA forward / backward / KV-cache decode.  Host-side C++ only enqueues kernels on the caller's
+// stream (no allocation, no sync), so a caller can capture any of these into a hipGraph.
+//
+// Reference call stacks: encode_audio clip_whisper_model.py:1067-1106 -> WhisperEncoder.forward
+// HF:models/whisper/modeling_whisper.py:592-646; encode_video :1108-1146 -> CLIPVisionModel.forward
+// HF:models/clip/modeling_clip.py:641-656; self.llm(...) :602-613 -> LlamaForCausalLM.forward
+// HF:models/llama/modeling_llama.py:435-488; loss.backward() trainer/clip_whisper_trainer.py:454.
+#include "common.h"
+#include "avllm_internal.h"
+
+namespace {
+
+struct Bump {
+    char* base; size_t cap; size_t off = 0; bool ok = true;
+    Bump(void* p, size_t c) : base((char*)p), cap(c) {}
+    void* take(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        if (a + bytes > cap) { ok = false; off = a + bytes; return base; }
+        off = a + bytes;
+        return base + a;
+    }
+};
+// dry-run sizing uses a null base and an unlimited cap
+inline size_t bump_size(const Bump& b) { return ((b.off + 255) & ~(size_t)255) + 256; }
+
+inline avllm_gemm_desc gemm_desc(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K) {
+    avllm_gemm_desc g = {};
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.dtype = dtype; g.alpha = 1.0f;
+    return g;
+}
+
+// ------------------------------------------------------------------ encoders
+struct EncBuf { void *x, *xn, *qkv, *att, *ff; };
+
+int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int heads, int ffn, int tokens, long items,
+                   float eps, int act, const EncBuf& b, bool cls_only_last, void* cls_out, void* xc, void* xcn, hipStream_t st) {
+    const long M = items * tokens;
+    const int hd = d / heads;
+    const size_t es = av_dtype_size(dtype);
+    for (int l = 0; l < layers; ++l) {
+        const avllm_enc_layer& P = L[l];
+        AV_TRY(av_layernorm(b.x, P.ln1_w, P.ln1_b, b.xn, M, d, eps, dtype, st));
+        avllm_gemm_desc g = gemm_desc(dtype, b.xn, d, P.wqkv, d, b.qkv, 3 * d, (int)M, 3 * d, d);
+        g.bias = P.bqkv;
+        AV_TRY(av_gemm(&g, st));
+        const char* qkv = (const char*)b.qkv;
+        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, b.att, nullptr, (int)items, tokens, tokens,
+                                heads, hd, 3 * d, 3 * d, 3 * d, d, 1.0f / sqrtf((float)hd), 0, dtype, 0, st));
+        if (cls_only_last && l == layers - 1) {
+            // only token 0 of the last block is consumed (clip_whisper_model.py:1141): finish the block on CLS rows
+            g = gemm_desc(dtype, b.att, (long)tokens * d, P.wo, d, xc, d, (int)items, d, d);
+            g.bias = P.bo; g.R = b.x; g.ldr = (long)tokens * d;
+            AV_TRY(av_gemm(&g, st));
+            AV_TRY(av_layernorm(xc, P.ln2_w, P.ln2_b, xcn, items, d, eps, dtype, st));
+            g = gemm_desc(dtype, xcn, d, P.w1, d, b.ff, ffn, (int)items, ffn, d);
+            g.bias = P.b1; g.act = act;
+            AV_TRY(av_gemm(&g, st));
+            g = gemm_desc(dtype, b.ff, ffn, P.w2, ffn, cls_out, d, (int)items, d, ffn);
+            g.bias = P.b2; g.R = xc; g.ldr = d;
+            AV_TRY(av_gemm(&g, st));
+            return AV_OK;
+        }
+        g = gemm_desc(dtype, b.att, d, P.wo, d, b.x, d, (int)M, d, d);
+        g.bias = P.bo; g.R = b.x; g.ldr = d;
+        AV_TRY(av_gemm(&g, st));
+        AV_TRY(av_layernorm(b.x, P.ln2_w, P.ln2_b, b.xn, M, d, eps, dtype, st));
+        g = gemm_desc(dtype, b.xn, d, P.w1, d, b.ff, ffn, (int)M, ffn, d);
+        g.bias = P.b1; g.act = act;
+        AV_TRY(av_gemm(&g, st));
+        g = gemm_desc(dtype, b.ff, ffn, P.w2, ffn, b.x, d, (int)M, d, ffn);
+        g.bias = P.b2; g.R = b.x; g.ldr = d;
+        AV_TRY(av_gemm(&g, st));
+    }
+    return AV_OK;
+}
+
+struct WhisperWs { void *cols1, *h1, *cols2; EncBuf e; };
+void carve_whisper(const avllm_whisper* w, int B, Bump& b, WhisperWs& s) {
+    const size_t es = av_dtype_size(w->dtype);
+    const long T2 = 2L * w->n_ctx, M = (long)B * w->n_ctx;
+    s.cols1 = b.take((size_t)B * T2 * w->k1pad * es);
+    s.h1 = b.take((size_t)B * T2 * w->d * es);
+    s.cols2 = b.take((size_t)M * 3 * w->d * es);
+    s.e.x = b.take((size_t)M * w->d * es);
+    s.e.xn = b.take((size_t)M * w->d * es);
+    s.e.qkv = b.take((size_t)M * 3 * w->d * es);
+    s.e.att = b.take((size_t)M * w->d * es);
+    s.e.ff = b.take((size_t)M * w->ffn * es);
+}
+
+struct ClipWs { void* cols; EncBuf e; void *xc, *xcn; };
+void carve_clip(const avllm_clip* c, int N, Bump& b, ClipWs& s, int& kpad) {
+    const size_t es = av_dtype_size(c->dtype);
+    const int g = c->image / c->patch;
+    kpad = (3 * c->patch * c->patch + 63) / 64 * 64;
+    const long M = (long)N * c->tokens;
+    s.cols = b.take((size_t)N * g * g * kpad * es);
+    s.e.x = b.take((size_t)M * c->d * es);
+    s.e.xn = b.take((size_t)M * c->d * es);
+    s.e.qkv = b.take((size_t)M * 3 * c->d * es);
+    s.e.att = b.take((size_t)M * c->d * es);
+    s.e.ff = b.take((size_t)M * c->ffn * es);
+    s.xc = b.take((size_t)N * c->d * es);
+    s.xcn = b.take((size_t)N * c->d * es);
+}
+
+// ------------------------------------------------------------------ llama
+struct LlamaLayerAct {
+    void *xn1, *qkv, *att, *tqkv, *to, *h1, *gu;
+    float *rstd1, *rstd2, *lse;
+};
+struct LlamaTrainWs {
+    void** resid;            // host array [layers+1] (lives in a std::vector owned by the caller frame)
+    LlamaLayerAct* act;      // host array [layers]
+    void *xn2, *hmid, *xf, *logits;
+    float *rstd_f, *row_lse, *delta;
+    // backward scratch
+    void *dres, *dxn, *dgu, *dhmid, *dqkv, *datt, *dtqkv, *dto;
+};
+
+void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs& w, void** resid, LlamaLayerAct* act) {
+    const size_t es = av_dtype_size(m->dtype);
+    const long M = (long)B * S;
+    const int d = m->d, f = m->ffn;
+    w.resid = resid; w.act = act;
+    for (int l = 0; l <= m->layers; ++l) resid[l] = b.take((size_t)M * d * es);
+    for (int l = 0; l < m->layers; ++l) {
+        LlamaLayerAct& a = act[l];
+        a.xn1 = b.take((size_t)M * d * es);
+        a.qkv = b.take((size_t)M * 3 * d * es);
+        a.att = b.take((size_t)M * d * es);
+        a.tqkv = b.take((size_t)M * 3 * AVLLM_LORA_PAD * es);
+        a.to = b.take((size_t)M * AVLLM_LORA_PAD * es);
+        a.h1 = b.take((size_t)M * d * es);
+        a.gu = b.take((size_t)M * 2 * f * es);
+        a.rstd1 = (float*)b.take((size_t)M * 4);
+        a.rstd2 = (float*)b.take((size_t)M * 4);
+        a.lse = (float*)b.take((size_t)B * m->heads * S * 4);
+    }
+    w.xn2 = b.take((size_t)M * d * es);
+    w.hmid = b.take((size_t)M * f * es);
+    w.xf = b.take((size_t)M * d * es);
+    w.logits = b.take((size_t)M * m->vocab * es);
+    w.rstd_f = (float*)b.take((size_t)M * 4);
+    w.row_lse = (float*)b.take((size_t)M * 4);
+    w.delta = (float*)b.take((size_t)B * m->heads * S * 4);
+    w.dres = b.take((size_t)M * d * es);
+    w.dxn = b.take((size_t)M * d * es);
+    w.dgu = b.take((size_t)M * 2 * f * es);
+    w.dhmid = b.take((size_t)M * f * es);
+    w.dqkv = b.take((size_t)M * 3 * d * es);
+    w.datt = b.take((size_t)M * d * es);
+    w.dtqkv = b.take((size_t)M * 3 * AVLLM_LORA_PAD * es);
+    w.dto = b.take((size_t)M * AVLLM_LORA_PAD * es);
+}
+
+int check_llama(const avllm_llama* m) {
+    AV_CHECK_ARG(m && m->layer && m->embed && m->norm_w && m->lm_head, "llama: null model fields");
+    AV_CHECK_ARG(m->d % m->heads == 0 && m->d % 64 == 0 && m->ffn % 64 == 0, "llama: d=%d ffn=%d must be multiples of 64", m->d, m->ffn);
+    AV_CHECK_ARG(m->layers > 0 && m->layers <= 256, "llama: layers=%d", m->layers);
+    return AV_OK;
+}
+
+// y[:, slice j] = x W_j^T (+ t_j B_j^T)
+int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long ldw, int K, int N, const avllm_lora_mod& lm,
+              void* t, long ldt, void* y, long ldy, const void* R, long ldr, int M, hipStream_t st) {
+    avllm_gemm_desc g;
+    const bool has = lm.A_pad != nullptr;
+    if (has) {
+        g = gemm_desc(m->dtype, x, ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
+        g.alpha = m->lora_scale;
+        AV_TRY(av_gemm(&g, st));
+    }
+    g = gemm_desc(m->dtype, x, ldx, W, ldw, y, ldy, M, N, K);
+    if (has) { g.A2 = t; g.lda2 = ldt; g.B2 = lm.B_pad; g.ldb2 = AVLLM_LORA_PAD; g.K2 = AVLLM_LORA_PAD; }
+    g.R = R; g.ldr = ldr;
+    return av_gemm(&g, st);
+}
+
+}  // namespace
+
+// =============================================================================================== Whisper
+extern "C" size_t avllm_whisper_workspace_bytes(const avllm_whisper* w, int32_t B) {
+    Bump b(nullptr, (size_t)-1);
+    WhisperWs s;
+    carve_whisper(w, B, b, s);
+    return bump_size(b);
+}
+
+extern "C" int avllm_whisper_encoder_fwd(const avllm_whisper* w, const float* mel, int32_t B, void* out, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AV_CHECK_ARG(w && mel && out && ws && B > 0, "whisper_encoder_fwd: null/empty");
+    AV_CHECK_ARG(w->d % w->heads == 0 && w->d % 64 == 0 && w->ffn % 64 == 0 && w->k1pad % 64 == 0 && w->k1pad >= 3 * w->n_mels,
+                 "whisper: d=%d ffn=%d k1pad=%d unsupported", w->d, w->ffn, w->k1pad);
+    Bump b(ws, ws_bytes);
+    WhisperWs s;
+    carve_whisper(w, B, b, s);
+    if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "whisper_encoder_fwd: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
+    const int dt = w->dtype, d = w->d, T2 = 2 * w->n_ctx;
+    const long M = (long)B * w->n_ctx;
+    AV_TRY(av_whisper_im2col1(mel, s.cols1, B, w->n_mels, T2, w->k1pad, dt, st));
+    avllm_gemm_desc g = gemm_desc(dt, s.cols1, w->k1pad, w->conv1_w, w->k1pad, s.h1, d, B * T2, d, w->k1pad);
+    g.bias = w->conv1_b; g.act = AV_ACT_GELU;
+    AV_TRY(av_gemm(&g, st));
+    AV_TRY(av_whisper_im2col2(s.h1, s.cols2, B, T2, d, dt, st));
+    g = gemm_desc(dt, s.cols2, 3 * d, w->conv2_w, 3 * d, s.e.x, d, (int)M, d, 3 * d);
+    g.bias = w->conv2_b; g.act = AV_ACT_GELU; g.R = w->pos; g.ldr = d; g.r_mod = w->n_ctx;
+    AV_TRY(av_gemm(&g, st));
+    AV_TRY(encoder_layers(dt, w->layer, w->layers, d, w->heads, w->ffn, w->n_ctx, B, 1e-5f, AV_ACT_GELU, s.e, false, nullptr,
+                          nullptr, nullptr, st));
+    return av_layernorm(s.e.x, w->lnf_w, w->lnf_b, out, M, d, 1e-5f, dt, st);
+}
+
+// =============================================================================================== CLIP
+extern "C" size_t avllm_clip_workspace_bytes(const avllm_clip* c, int32_t N) {
+    Bump b(nullptr, (size_t)-1);
+    ClipWs s; int kpad;
+    carve_clip(c, N, b, s, kpad);
+    return bump_size(b);
+}
+
+extern "C" int avllm_clip_vision_cls_fwd(const avllm_clip* c, const float* frames, int32_t N, void* cls, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AV_CHECK_ARG(c && frames && cls && ws && N > 0, "clip_vision_cls_fwd: null/empty");
+    const int g1 = c->image / c->patch;
+    AV_CHECK_ARG(c->tokens == g1 * g1 + 1 && c->d % c->heads == 0 && c->d % 64 == 0 && c->ffn % 64 == 0,
+                 "clip: tokens=%d d=%d ffn=%d inconsistent", c->tokens, c->d, c->ffn);
+    Bump b(ws, ws_bytes);
+    ClipWs s; int kpad;
+    carve_clip(c, N, b, s, kpad);
+    if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "clip_vision_cls_fwd: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
+    const int dt = c->dtype, d = c->d, np = g1 * g1;
+    const size_t es = av_dtype_size(dt);
+    AV_TRY(av_clip_patchify(frames, s.cols, N, c->image, c->patch, kpad, dt, st));
+    // patch embedding + position embedding of the patch tokens, scattered to rows 1.. of each frame
+    avllm_gemm_desc g = gemm_desc(dt, s.cols, kpad, c->patch_w, kpad, s.e.xn, d, N * np, d, kpad);
+    g.R = (const char*)c->pos + (size_t)d * es; g.ldr = d; g.r_mod = np;
+    g.g_in = np; g.g_out = c->tokens; g.g_off = 1;
+    AV_TRY(av_gemm(&g, st));
+    AV_TRY(av_clip_cls_rows(c->class_emb, c->pos, s.e.xn, N, c->tokens, d, dt, st));
+    AV_TRY(av_layernorm(s.e.xn, c->pre_ln_w, c->pre_ln_b, s.e.x, (long)N * c->tokens, d, c->eps, dt, st));
+    return encoder_layers(dt, c->layer, c->layers, d, c->heads, c->ffn, c->tokens, N, c->eps, AV_ACT_QUICK_GELU, s.e, true, cls,
+                          s.xc, s.xcn, st);
+}
+
+// =============================================================================================== Llama train
+extern "C" size_t avllm_llama_train_workspace_bytes(const avllm_llama* m, int32_t B, int32_t S) {
+    Bump b(nullptr, (size_t)-1);
+    LlamaTrainWs w;
+    void* resid[257]; LlamaLayerAct act[256];
+    if (!m || m->layers > 256) return 0;
+    carve_llama_train(m, B, S, b, w, resid, act);
+    return bump_size(b);
+}
+
+extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, const int64_t* labels, int32_t B, int32_t S,
+                                         void* logits_out, float* loss_sum, float* count, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AV_TRY(check_llama(m));
+    AV_CHECK_ARG(x && ws && B > 0 && S > 0, "llama_lora_fwd_loss: null/empty");
+    AV_CHECK_ARG(!labels || (loss_sum && count), "llama_lora_fwd_loss: labels need loss_sum/count");
+    Bump b(ws, ws_bytes);
+    LlamaTrainWs w;
+    void* resid[257]; LlamaLayerAct act[256];
+    carve_llama_train(m, B, S, b, w, resid, act);
+    if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_lora_fwd_loss: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
+    const int dt = m->dtype, d = m->d, f = m->ffn, H = m->heads, hd = d / H;
+    const size_t es = av_dtype_size(dt);
+    const int M = B * S;
+    AV_HIP(hipMemcpyAsync(resid[0], x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < m->layers; ++l) {
+        const avllm_llama_layer& P = m->layer[l];
+        LlamaLayerAct& a = act[l];
+        AV_TRY(av_rmsnorm_fwd(resid[l], P.ln1_w, a.xn1, a.rstd1, M, d, m->eps, dt, st));
+        for (int j = 0; j < 3; ++j) {
+            AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j],
+                             (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
+                             (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));
+        }
+        AV_TRY(av_rope(a.qkv, 3 * d, M, S, H, hd, 0, m->theta, 0, dt, st));
+        AV_TRY(av_rope((char*)a.qkv + (size_t)d * es, 3 * d, M, S, H, hd, 0, m->theta, 0, dt, st));
+        const char* qkv = (const char*)a.qkv;
+        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, a.lse, B, S, S, H, hd, 3 * d, 3 * d,
+                                3 * d, d, 1.0f / sqrtf((float)hd), 1, dt, 0, st));
+        AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st));
+        AV_TRY(av_rmsnorm_fwd(a.h1, P.ln2_w, w.xn2, a.rstd2, M, d, m->eps, dt, st));
+        avllm_gemm_desc g = gemm_desc(dt, w.xn2, d, P.wgu, d, a.gu, 2 * f, M, 2 * f, d);
+        AV_TRY(av_gemm(&g, st));
+        AV_TRY(av_swiglu_fwd(a.gu, w.hmid, M, f, dt, st));
+        g = gemm_desc(dt, w.hmid, f, P.wdown, f, resid[l + 1], d, M, d, f);
+        g.R = a.h1; g.ldr = d;
+        AV_TRY(av_gemm(&g, st));
+    }
+    AV_TRY(av_rmsnorm_fwd(resid[m->layers], m->norm_w, w.xf, w.rstd_f, M, d, m->eps, dt, st));
+    avllm_gemm_desc g = gemm_desc(dt, w.xf, d, m->lm_head, d, w.logits, m->vocab, M, m->vocab, d);
+    AV_TRY(av_gemm(&g, st));
+    if (logits_out) AV_HIP(hipMemcpyAsync(logits_out, w.logits, (size_t)M * m->vocab * es, hipMemcpyDeviceToDevice, st));
+    if (labels) AV_TRY(av_ce_fwd(w.logits, m->vocab, labels, B, S, m->vocab, w.row_lse, loss_sum, count, dt, st));
+    return AV_OK;
+}
+
+extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels, int32_t B, int32_t S, const float* count,
+                                    float grad_scale, void* ws, size_t ws_bytes, avllm_layer_cb after_layer, void* user,
+                                    void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AV_TRY(check_llama(m));
+    AV_CHECK_ARG(labels && count && ws && m->lm_head_t, "llama_lora_bwd: null (training needs the transposed weight images)");
+    Bump b(ws, ws_bytes);
+    LlamaTrainWs w;
+    void* resid[257]; LlamaLayerAct act[256];
+    carve_llama_train(m, B, S, b, w, resid, act);
+    if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_lora_bwd: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
+    const int dt = m->dtype, d = m->d, f = m->ffn, H = m->heads, hd = d / H, V = m->vocab;
+    const size_t es = av_dtype_size(dt);
+    const int M = B * S, R = m->lora_r;
+    const float sc = m->lora_scale;
+    AV_TRY(av_ce_bwd(w.logits, V, labels, w.row_lse, count, grad_scale, w.logits, B, S, V, dt, st));
+    avllm_gemm_desc g = gemm_desc(dt, w.logits, V, m->lm_head_t, V, w.dxn, d, M, d, V);
+    AV_CHECK_ARG(V % 64 == 0, "llama_lora_bwd: vocab %d must be a multiple of 64", V);
+    AV_TRY(av_gemm(&g, st));
+    AV_TRY(av_rmsnorm_bwd(w.dxn, resid[m->layers], m->norm_w, w.rstd_f, nullptr, w.dres, M, d, dt, st));
+    for (int l = m->layers - 1; l >= 0; --l) {
+        const avllm_llama_layer& P = m->layer[l];
+        LlamaLayerAct& a = act[l];
+        AV_CHECK_ARG(P.wqkv_t && P.wo_t && P.wgu_t && P.wdown_t, "llama_lora_bwd: layer %d has no transposed weights", l);
+        // ---- MLP: resid[l+1] = h1 + down(silu(g)*u)
+        g = gemm_desc(dt, w.dres, d, P.wdown_t, d, w.dhmid, f, M, f, d);
+        AV_TRY(av_gemm(&g, st));
+        AV_TRY(av_swiglu_bwd(w.dhmid, a.gu, w.dgu, M, f, dt, st));
+        g = gemm_desc(dt, w.dgu, 2 * f, P.wgu_t, 2 * f, w.dxn, d, M, d, 2 * f);
+        AV_TRY(av_gemm(&g, st));
+        AV_TRY(av_rmsnorm_bwd(w.dxn, a.h1, P.ln2_w, a.rstd2, w.dres, w.dres, M, d, dt, st));      // dres = d h1
+        // ---- o_proj (+LoRA): h1 = resid[l] + att Wo^T + to Bo^T
+        const avllm_lora_mod& lo = P.lora[3];
+        g = gemm_desc(dt, w.dres, d, P.wo_t, d, w.datt, d, M, d, d);
+        if (lo.A_pad) {
+            AV_TRY(av_gemm_tn(w.dres, d, d, a.to, AVLLM_LORA_PAD, R, M, lo.gB, R, 1.0f, dt, st));
+            avllm_gemm_desc gt = gemm_desc(dt, w.dres, d, lo.BT_pad, d, w.dto, AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, d);
+            gt.alpha = sc;
+            AV_TRY(av_gemm(&gt, st));
+            AV_TRY(av_gemm_tn(w.dto, AVLLM_LORA_PAD, R, a.att, d, d, M, lo.gA, d, 1.0f, dt, st));
+            g.A2 = w.dto; g.lda2 = AVLLM_LORA_PAD; g.B2 = lo.AT_pad; g.ldb2 = lo.ld_at; g.K2 = AVLLM_LORA_PAD;
+        }
+        AV_TRY(av_gemm(&g, st));
+        // ---- attention
+        const char* qkv = (const char*)a.qkv;
+        char* dqkv = (char*)w.dqkv;
+        AV_TRY(av_attention_bwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, w.datt, a.lse, dqkv, dqkv + (size_t)d * es,
+                                dqkv + (size_t)2 * d * es, w.delta, B, S, H, hd, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
+                                1.0f / sqrtf((float)hd), 1, dt, 0, st));
+        AV_TRY(av_rope(dqkv, 3 * d, M, S, H, hd, 0, m->theta, 1, dt, st));
+        AV_TRY(av_rope(dqkv + (size_t)d * es, 3 * d, M, S, H, hd, 0, m->theta, 1, dt, st));
+        // ---- q,k,v projections (+LoRA)
+        bool any = false, contiguous = true;
+        for (int j = 0; j < 3; ++j) {
+            const avllm_lora_mod& lj = P.lora[j];
+            if (!lj.A_pad) { contiguous = false; continue; }
+            any = true;
+            const char* dy = dqkv + (size_t)j * d * es;
+            char* dtj = (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es;
+            AV_TRY(av_gemm_tn(dy, 3 * d, d, (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD, R, M, lj.gB, R, 1.0f, dt, st));
+            avllm_gemm_desc gt = gemm_desc(dt, dy, 3 * d, lj.BT_pad, d, dtj, 3 * AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, d);
+            gt.alpha = sc;
+            AV_TRY(av_gemm(&gt, st));
+            AV_TRY(av_gemm_tn(dtj, 3 * AVLLM_LORA_PAD, R, a.xn1, d, d, M, lj.gA, d, 1.0f, dt, st));
+            if (lj.ld_at != 3 * AVLLM_LORA_PAD ||
+                (const char*)lj.AT_pad != (const char*)P.lora[0].AT_pad + (size_t)j * AVLLM_LORA_PAD * es) contiguous = false;
+        }
+        if (l > 0) {      // d(inputs_embeds) is not needed: encoders/connectors are frozen
+            AV_CHECK_ARG(!any || contiguous, "llama_lora_bwd: q/k/v AT_pad images must be the three 64-column slices of one [d,192] matrix");
+            g = gemm_desc(dt, w.dqkv, 3 * d, P.wqkv_t, 3 * d, w.dxn, d, M, d, 3 * d);
+            if (any) { g.A2 = w.dtqkv; g.lda2 = 3 * AVLLM_LORA_PAD; g.B2 = P.lora[0].AT_pad; g.ldb2 = 3 * AVLLM_LORA_PAD; g.K2 = 3 * AVLLM_LORA_PAD; }
+            AV_TRY(av_gemm(&g, st));
+            AV_TRY(av_rmsnorm_bwd(w.dxn, resid[l], P.ln1_w, a.rstd1, w.dres, w.dres, M, d, dt, st));
+        }
+        if (after_layer) after_layer(l, user);
+    }
+    return AV_OK;
+}
+
+// =============================================================================================== Llama inference
+namespace {
+struct LlamaInferWs { void *x, *xn, *qkv, *att, *t, *gu, *hmid, *logits; float* lse; };
+void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs& w, bool all_logits) {
+    const size_t es = av_dtype_size(m->dtype);
+    const long M = (long)B * S;
+    w.x = b.take((size_t)M * m->d * es);
+    w.xn = b.take((size_t)M * m->d * es);
+    w.qkv = b.take((size_t)M * 3 * m->d * es);
+    w.att = b.take((size_t)M * m->d * es);
+    w.t = b.take((size_t)M * AVLLM_LORA_PAD * es);
+    w.gu = b.take((size_t)M * 2 * m->ffn * es);
+    w.hmid = b.take((size_t)M * m->ffn * es);
+    w.logits = b.take((size_t)(all_logits ? M : B) * m->vocab * 4);
+}
+
+// one decoder block on M = B*S rows at positions [pos0, pos0+S); K/V appended to the cache
+int llama_infer_layer(const avllm_llama* m, int l, LlamaInferWs& w, int B, int S, int pos0, void* kc, void* vc, int Tmax, hipStream_t st) {
+    const avllm_llama_layer& P = m->layer[l];
+    const int dt = m->dtype, d = m->d, f = m->ffn, H = m->heads, hd = d / H, M = B * S;
+    const size_t es = av_dtype_size(dt);
+    char* kcl = (char*)kc + (size_t)l * B * Tmax * d * es;
+    char* vcl = (char*)vc + (size_t)l * B * Tmax * d * es;
+    AV_TRY(av_rmsnorm_fwd(w.x, P.ln1_w, w.xn, nullptr, M, d, m->eps, dt, st));
+    for (int j = 0; j < 3; ++j)
+        AV_TRY(lora_proj(m, w.xn, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j], w.t, AVLLM_LORA_PAD,
+                         (char*)w.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));
+    char* qkv = (char*)w.qkv;
+    AV_TRY(av_rope(qkv, 3 * d, M, S, H, hd, pos0, m->theta, 0, dt, st));
+    AV_TRY(av_rope(qkv + (size_t)d * es, 3 * d, M, S, H, hd, pos0, m->theta, 0, dt, st));
+    AV_TRY(av_kv_append(qkv + (size_t)d * es, qkv + (size_t)2 * d * es, 3 * d, kcl, vcl, B, S, pos0, Tmax, d, dt, st));
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (S == 1) {
+        AV_TRY(av_attention_decode(qkv, 3 * d, kcl, vcl, w.att, d, B, H, hd, pos0 + 1, Tmax, scale, dt, st));
+    } else {
+        AV_CHECK_ARG(pos0 == 0, "llama prefill must start at position 0");
+        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, w.att, nullptr, B, S, S, H, hd, 3 * d, 3 * d, 3 * d,
+                                d, scale, 1, dt, 0, st));
+    }
+    AV_TRY(lora_proj(m, w.att, d, P.wo, d, d, d, P.lora[3], w.t, AVLLM_LORA_PAD, w.x, d, w.x, d, M, st));
+    AV_TRY(av_rmsnorm_fwd(w.x, P.ln2_w, w.xn, nullptr, M, d, m->eps, dt, st));
+    avllm_gemm_desc g = gemm_desc(dt, w.xn, d, P.wgu, d, w.gu, 2 * f, M, 2 * f, d);
+    AV_TRY(av_gemm(&g, st));
+    AV_TRY(av_swiglu_fwd(w.gu, w.hmid, M, f, dt, st));
+    g = gemm_desc(dt, w.hmid, f, P.wdown, f, w.x, d, M, d, f);
+    g.R = w.x; g.ldr = d;
+    return av_gemm(&g, st);
+}
+}  // namespace
+
+extern "C" size_t avllm_llama_infer_workspace_bytes(const avllm_llama* m, int32_t B, int32_t S) {
+    Bump b(nullptr, (size_t)-1);
+    LlamaInferWs w;
+    carve_llama_infer(m, B, S, b, w, true);
+    return bump_size(b);
+}
+
+extern "C" int avllm_llama_prefill(const avllm_llama* m, const void* x, int32_t B, int32_t S, void* kcache, void* vcache,
+                                   int32_t Tmax, float* logits_last, void* all_logits, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AV_TRY(check_llama(m));
+    AV_CHECK_ARG(x && kcache && vcache && ws && B > 0 && S > 0 && S <= Tmax, "llama_prefill: bad args (S=%d Tmax=%d)", S, Tmax);
+    Bump b(ws, ws_bytes);
+    LlamaInferWs w;
+    carve_llama_infer(m, B, S, b, w, true);
+    if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_prefill: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
+    const int dt = m->dtype, d = m->d, M = B * S;
+    const size_t es = av_dtype_size(dt);
+    AV_HIP(hipMemcpyAsync(w.x, x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < m->layers; ++l) AV_TRY(llama_infer_layer(m, l, w, B, S, 0, kcache, vcache, Tmax, st));
+    AV_TRY(av_rmsnorm_fwd(w.x, m->norm_w, w.xn, nullptr, M, d, m->eps, dt, st));
+    if (all_logits) {     // eval-mode forward(): logits for every position, in model dtype
+        avllm_gemm_desc g = gemm_desc(dt, w.xn, d, m->lm_head, d, all_logits, m->vocab, M, m->vocab, d);
+        AV_TRY(av_gemm(&g, st));
+    }
+    if (logits_last) {    // rows S-1, 2S-1, ... -> [B,vocab] f32
+        avllm_gemm_desc g = gemm_desc(dt, (const char*)w.xn + (size_t)(S - 1) * d * es, (long)S * d, m->lm_head, d, logits_last, m->vocab, B, m->vocab, d);
+        g.out_f32 = 1;
+        AV_TRY(av_gemm(&g, st));
+    }
+    return AV_OK;
+}
+
+extern "C" int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, void* kcache,
+                                       void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AV_TRY(check_llama(m));
+    AV_CHECK_ARG(ids && kcache && vcache && logits && ws && B > 0 && pos >= 0 && pos < Tmax, "llama_decode_step: bad args (pos=%d Tmax=%d)", pos, Tmax);
+    Bump b(ws, ws_bytes);
+    LlamaInferWs w;
+    carve_llama_infer(m, B, 1, b, w, true);
+    if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_decode_step: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
+    const int dt = m->dtype, d = m->d;
+    AV_TRY(av_embedding(m->embed, ids, w.x, B, d, dt, st));
+    for (int l = 0; l < m->layers; ++l) AV_TRY(llama_infer_layer(m, l, w, B, 1, pos, kcache, vcache, Tmax, st));
+    AV_TRY(av_rmsnorm_fwd(w.x, m->norm_w, w.xn, nullptr, B, d, m->eps, dt, st));
+    avllm_gemm_desc g = gemm_desc(dt, w.xn, d, m->lm_head, d, logits, m->vocab, B, m->vocab, d);
+    g.out_f32 = 1;
+    return av_gemm(&g, st);
+}

@@ -1,0 +1,269 @@
+// NT GEMM for gfx950:  C[M,N] = act(alpha * (A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T) + bias[N]) + R
+//
+// Every dense contraction of the hot path is this one shape (activations x frozen weights stored
+// [out,in], exactly as nn.Linear holds them -- reference call sites: whisper/clip/llama projections,
+// SURVEY.md §2 "Stock ops").  The optional second K segment carries the LoRA up-projection
+// (A2 = x.A^T padded to 64 columns, B2 = lora_B padded to 64 columns) so the adapter costs one extra
+// K-tile inside the same accumulator instead of a second pass over C (peft lora.Linear; reference wrap
+// src/clip_whisper/models/clip_whisper_model.py:961-1005).
+//
+// bf16 kernel: 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 accumulators.
+//   * both operands staged global->LDS by `global_load_lds_dwordx4` (no VGPR round trip), two LDS
+//     buffers, one barrier per K-tile; LDS image is lane-linear, bank conflicts removed by XOR-ing the
+//     16-B chunk index with (row & 7) on the SOURCE address and again on the ds_read_b128 address.
+//   * MFMA is issued with the weight fragment as the A operand (acc = W_frag x X_frag), so each lane ends
+//     with 4 consecutive output columns of one row -> one 8-byte bf16 store per accumulator.
+//   * XCD-aware block->tile map: the 8 XCDs get contiguous tile ranges so that neighbours share panels in L2.
+// f32 kernel (strict-parity mode): 64x64x16 tile on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+#include "common.h"
+#include "avllm_internal.h"
+
+namespace {
+
+struct EpiParams {
+    void* C; long ldc; int out_f32;
+    const void* bias; const void* R; long ldr; int r_mod;
+    int g_in, g_out, g_off;
+    float alpha; int act;
+    int M, N;
+};
+
+// v[4] = 4 consecutive output columns n0..n0+3 of logical row m
+template <typename T>
+__device__ __forceinline__ void epilogue_store4(const EpiParams& e, int m, int n0, float (&v)[4]) {
+    if (m >= e.M || n0 >= e.N) return;
+    const bool full = (n0 + 3 < e.N);
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.bias) {
+        const T* bp = (const T*)e.bias + n0;
+        if (full) { load_f<4>(bp, b); } else { for (int i = 0; i < 4 && n0 + i < e.N; ++i) b[i] = to_f(bp[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i] * e.alpha + b[i], e.act);
+    if (e.R) {
+        const long rr = e.r_mod > 0 ? (m % e.r_mod) : m;
+        const T* rp = (const T*)e.R + rr * e.ldr + n0;
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (full) { load_f<4>(rp, r); } else { for (int i = 0; i < 4 && n0 + i < e.N; ++i) r[i] = to_f(rp[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+    long orow = m;
+    if (e.g_in > 0) orow = (long)(m / e.g_in) * e.g_out + e.g_off + (m % e.g_in);
+    if (e.out_f32) {
+        float* cp = (float*)e.C + orow * e.ldc + n0;
+        if (full) store_f<4>(cp, v); else for (int i = 0; i < 4 && n0 + i < e.N; ++i) cp[i] = v[i];
+    } else {
+        T* cp = (T*)e.C + orow * e.ldc + n0;
+        if (full) store_f<4>(cp, v); else for (int i = 0; i < 4 && n0 + i < e.N; ++i) cp[i] = from_f<T>(v[i]);
+    }
+}
+
+// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
+// range of logical tile ids.  Bijective for any grid size (cdna guide §5, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if (tiles_m <= 32) { tm = id % tiles_m; tn = id / tiles_m; }      // weights streamed once, all row tiles adjacent
+    else               { tn = id % tiles_n; tm = id / tiles_n; }      // activations streamed once
+}
+
+// ------------------------------------------------------------------------------------------ bf16
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
+
+struct GemmArgs {
+    const bf16* A; const bf16* B; const bf16* A2; const bf16* B2;
+    long lda, ldb, lda2, ldb2;
+    int K, K2;
+    EpiParams e;
+};
+
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, long ld, int row0, int rows_max,
+                                           int k0, char* lds, int wave, int lane) {
+    // one wave-instruction = 8 rows x 128 B.  4 waves x 4 passes = 128 rows.
+    const int rsub = lane >> 3;                       // row inside the 8-row group == (row & 7)
+    const int chunk_src = (lane & 7) ^ rsub;          // inverse swizzle on the source
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = p * 32 + wave * 8 + rsub;
+        int gr = row0 + r;
+        gr = gr < rows_max ? gr : rows_max - 1;       // clamp: rows past the edge are never stored
+        const bf16* src = base + (long)gr * ld + k0 + chunk_src * 8;
+        char* dst = lds + (p * 32 + wave * 8) * 128;  // wave-uniform base; hardware adds lane*16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile + B tile) = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (g.e.M + BM - 1) / BM, tiles_n = (g.e.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;
+    auto stage = [&](int t, int buf) {
+        char* a_lds = smem + buf * (2 * TILE_BYTES);
+        char* b_lds = a_lds + TILE_BYTES;
+        if (t < nt1) {
+            stage_tile(g.A, g.lda, m0, g.e.M, t * BK, a_lds, wave, lane);
+            stage_tile(g.B, g.ldb, n0, g.e.N, t * BK, b_lds, wave, lane);
+        } else {
+            stage_tile(g.A2, g.lda2, m0, g.e.M, (t - nt1) * BK, a_lds, wave, lane);
+            stage_tile(g.B2, g.ldb2, n0, g.e.N, (t - nt1) * BK, b_lds, wave, lane);
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();                                   // hipcc drains vmcnt(0) before the barrier
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        const char* a_lds = smem + cur * (2 * TILE_BYTES);
+        const char* b_lds = a_lds + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xa[4], wb[4];
+            const int chunk = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + fr;
+                xa[i] = *(const bf16x8*)(a_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + fr;
+                wb[j] = *(const bf16x8*)(b_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // acc[i][j][reg]: output row m = m0 + wm*64 + i*16 + (lane&15); column n = n0 + wn*64 + j*16 + (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ f32
+constexpr int FM = 64, FN = 64, FK = 16, FLD = FK + 1;
+
+struct GemmArgsF {
+    const float* A; const float* B; const float* A2; const float* B2;
+    long lda, ldb, lda2, ldb2;
+    int K, K2;
+    EpiParams e;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
+    __shared__ float As[FM * FLD], Bs[FN * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (g.e.M + FM - 1) / FM, tiles_n = (g.e.N + FN - 1) / FN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * FM, n0 = tn * FN;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nt1 = g.K / FK, nt = nt1 + g.K2 / FK;
+    const int lr = tid >> 2, lc = (tid & 3) * 4;       // 64 rows x 4 float4 per operand tile
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        const float* Ap; const float* Bp; long la, lb; int k0;
+        if (t < nt1) { Ap = g.A; Bp = g.B; la = g.lda; lb = g.ldb; k0 = t * FK; }
+        else { Ap = g.A2; Bp = g.B2; la = g.lda2; lb = g.ldb2; k0 = (t - nt1) * FK; }
+        int ar = m0 + lr; ar = ar < g.e.M ? ar : g.e.M - 1;
+        int br = n0 + lr; br = br < g.e.N ? br : g.e.N - 1;
+        const f32x4 av = *(const f32x4*)(Ap + (long)ar * la + k0 + lc);
+        const f32x4 bv = *(const f32x4*)(Bp + (long)br * lb + k0 + lc);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[lr * FLD + lc + i] = av[i]; Bs[lr * FLD + lc + i] = bv[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < FK / 4; ++ks) {
+            float xa[2], wb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xa[i] = As[(wm * 32 + i * 16 + fr) * FLD + ks * 4 + fq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wb[j] = Bs[(wn * 32 + j * 16 + fr) * FLD + ks * 4 + fq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<float>(g.e, m, n0 + wn * 32 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
+}  // namespace
+
+int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
+    AV_CHECK_ARG(d && d->A && d->B && d->C, "gemm: null operand");
+    AV_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    AV_CHECK_ARG(d->K % 64 == 0 && d->K2 % 64 == 0, "gemm: K (%d) and K2 (%d) must be multiples of 64", d->K, d->K2);
+    AV_CHECK_ARG(d->K2 == 0 || (d->A2 && d->B2), "gemm: K2>0 needs A2/B2");
+    AV_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "gemm: leading dims must keep 16-byte rows");
+    AV_CHECK_ARG(d->dtype == AV_F32 || d->dtype == AV_BF16, "gemm: dtype %d", d->dtype);
+    EpiParams e;
+    e.C = d->C; e.ldc = d->ldc; e.out_f32 = d->out_f32 || d->dtype == AV_F32; e.bias = d->bias; e.R = d->R; e.ldr = d->ldr;
+    e.r_mod = d->r_mod; e.g_in = d->g_in; e.g_out = d->g_out; e.g_off = d->g_off;
+    e.alpha = d->alpha; e.act = d->act; e.M = d->M; e.N = d->N;
+    if (d->dtype == AV_BF16) {
+        GemmArgs g;
+        g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
+        g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
+        const int tiles = av_cdiv(d->M, BM) * av_cdiv(d->N, BN);
+        static bool attr_set = false;
+        if (!attr_set) {
+            AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, st, g);
+    } else {
+        GemmArgsF g;
+        g.A = (const float*)d->A; g.B = (const float*)d->B; g.A2 = (const float*)d->A2; g.B2 = (const float*)d->B2;
+        g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
+        const int tiles = av_cdiv(d->M, FM) * av_cdiv(d->N, FN);
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, st, g);
+    }
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

@@ -1,0 +1,228 @@
+/*
+ * avllm.h -- C ABI of libavllm.so, the MI355X (gfx950) implementation of the AV->LLM hot path of
+ * rishabhjain16/audio-visual-llm `src/clip_whisper`.
+ *
+ * The reference has no FFI of its own: its seam is the Python class surface
+ * (src/clip_whisper/models/clip_whisper_model.py, trainer/clip_whisper_trainer.py).  The entry points
+ * below are what a ctypes binding under those classes calls; each cites the reference interface it
+ * replaces.  Plain pointers and sizes only: every `const void*`/`void*` is a DEVICE pointer unless the
+ * comment says host; `stream` is a hipStream_t passed as void* (NULL = default stream).  All functions
+ * are asynchronous on `stream`, return 0 on success or an AVLLM_ERR_* code, and leave a message for
+ * avllm_last_error() (thread local).  No function allocates device memory: scratch comes from the
+ * caller-provided workspace.
+ *
+ * dtype: AVLLM_F32 (strict-parity mode, fp32 MFMA) or AVLLM_BF16 (bf16 storage, fp32 accumulate).
+ */
+#ifndef AVLLM_H
+#define AVLLM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVLLM_F32 0
+#define AVLLM_BF16 1
+#define AVLLM_ACT_NONE 0
+#define AVLLM_ACT_GELU 1        /* erf GELU  (Whisper, HF:models/whisper/modeling_whisper.py:618-619,:405) */
+#define AVLLM_ACT_QUICK_GELU 2  /* x*sigmoid(1.702x) (CLIP, HF:models/clip/modeling_clip.py:346-350) */
+#define AVLLM_ACT_SILU 3
+#define AVLLM_LORA_PAD 64       /* LoRA rank is stored padded to this many columns */
+
+const char* avllm_last_error(void);
+int avllm_version(void);
+
+/* ---------------------------------------------------------------- op level -------------------- */
+
+/* C[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias) + R ; replaces every nn.Linear / F.linear on the path
+ * (modality_connector.py:43-44; HF q/k/v/out/fc1/fc2/gate/up/down/lm_head) incl. the peft LoRA add. */
+typedef struct avllm_gemm_desc {
+    const void* A;  const void* B;      /* A [M,K] row stride lda; B [N,K] row stride ldb (nn.Linear weight) */
+    const void* A2; const void* B2;     /* optional second K segment [M,K2] / [N,K2] (LoRA), NULL if K2==0 */
+    void* C;                            /* [M,N] row stride ldc */
+    const void* bias;                   /* [N] in `dtype`, or NULL */
+    const void* R;                      /* residual [M,N] (or [r_mod,N]) in `dtype`, or NULL */
+    int64_t lda, ldb, lda2, ldb2, ldc, ldr;
+    int32_t M, N, K, K2;                /* K, K2 multiples of 64 */
+    int32_t dtype;                      /* of A,B,A2,B2,bias,R (and C unless out_f32) */
+    int32_t out_f32;                    /* store C as float even in bf16 mode */
+    int32_t act;
+    float alpha;
+    int32_t r_mod;                      /* >0: residual row = m % r_mod (broadcast position embeddings) */
+    int32_t g_in, g_out, g_off;         /* g_in>0: output row = (m/g_in)*g_out + g_off + m%g_in */
+} avllm_gemm_desc;
+int avllm_gemm(const avllm_gemm_desc* d, void* stream);
+
+/* out[I,J] (f32, row stride ldo) += alpha * sum_m P[m,i]*Q[m,j]; LoRA dA/dB (autograd of peft lora.Linear) */
+int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
+                  float* out, int64_t ldo, float alpha, int32_t dtype, void* stream);
+
+/* nn.LayerNorm (HF whisper :379-413, clip :362-384) */
+int avllm_layernorm(const void* x, const void* w, const void* b, void* y, int64_t rows, int32_t d, float eps,
+                    int32_t dtype, void* stream);
+/* LlamaRMSNorm fwd (HF:models/llama/modeling_llama.py:62-67); rstd [rows] optional */
+int avllm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t d, float eps,
+                      int32_t dtype, void* stream);
+/* dx_out = dres_in + d(rmsnorm)/dx . dy   (dres_in may be NULL, dx_out may alias dres_in) */
+int avllm_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres_in,
+                      void* dx_out, int64_t rows, int32_t d, int32_t dtype, void* stream);
+/* rotary embedding in place on [rows = B*T, heads, hd] slices (row stride ld elements); position = pos0 + row % T;
+ * inverse=1 applies the transpose rotation (backward).  HF:models/llama/modeling_llama.py:129-160 */
+int avllm_rope(void* x, int64_t ld, int64_t rows, int32_t T, int32_t heads, int32_t hd, int32_t pos0, float theta,
+               int32_t inverse, int32_t dtype, void* stream);
+/* h = silu(g)*u with gu = [g | u] ([M,2F]); HF:models/llama/modeling_llama.py:175 */
+int avllm_swiglu_fwd(const void* gu, void* h, int64_t M, int32_t F, int32_t dtype, void* stream);
+int avllm_swiglu_bwd(const void* dh, const void* gu, void* dgu, int64_t M, int32_t F, int32_t dtype, void* stream);
+/* softmax(QK^T*scale [+causal]) V.  q/k/v/o: row = token (b*T+t), head h at column h*hd; row strides in elements.
+ * lse [B,H,Tq] (natural log) optional.  impl 0 = MFMA flash kernel (bf16 only), 1 = reference-grade scalar kernel.
+ * HF eager_attention_forward: whisper :215-238, clip :259-277, llama sdpa path. */
+int avllm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t Tq,
+                        int32_t Tk, int32_t H, int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                        float scale, int32_t causal, int32_t dtype, int32_t impl, void* stream);
+int avllm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                        const float* lse, void* dq, void* dk, void* dv, float* delta_ws, int32_t B, int32_t T,
+                        int32_t H, int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq,
+                        int64_t lddk, int64_t lddv, float scale, int32_t causal, int32_t dtype, int32_t impl,
+                        void* stream);
+/* shifted causal-LM cross entropy (HF:loss/loss_utils.py:49-71): row (b,t) is scored against labels[b,t+1],
+ * ignore_index -100 and the last position.  loss_sum/count are ACCUMULATED (zero them first). row_lse [B*T]. */
+int avllm_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V,
+                 float* row_lse, float* loss_sum, float* count, int32_t dtype, void* stream);
+/* dlogits = (softmax - onehot) * (grad_scale / *count) for scored rows, 0 elsewhere (may alias logits) */
+int avllm_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* row_lse, const float* count,
+                 float grad_scale, void* dlogits, int32_t B, int32_t T, int32_t V, int32_t dtype, void* stream);
+int avllm_argmax_rows(const void* logits, int64_t ld, int64_t rows, int32_t V, int64_t* out, int32_t dtype, void* stream);
+/* out[i,:] = table[ids[i],:] ; llm.get_input_embeddings() (clip_whisper_model.py:464-487) */
+int avllm_embedding(const void* table, const int64_t* ids, void* out, int64_t n, int32_t d, int32_t dtype, void* stream);
+int avllm_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
+
+/* Whisper conv stem im2col (HF:models/whisper/modeling_whisper.py:618-619).
+ * conv1: mel f32 [B,80,T] -> cols [B*T, Kpad] with column c*3+kw = mel[b,c,t+kw-1] (zero padded, Kpad>=240)
+ * conv2: h [B*T,d] -> cols [B*(T/2), 3d] with column kw*d+c = h[b,2t'+kw-1,c]                                */
+int avllm_whisper_im2col1(const float* mel, void* cols, int32_t B, int32_t n_mels, int32_t T, int32_t Kpad,
+                          int32_t dtype, void* stream);
+int avllm_whisper_im2col2(const void* h, void* cols, int32_t B, int32_t T, int32_t d, int32_t dtype, void* stream);
+/* CLIP patchify (HF:models/clip/modeling_clip.py:202-218): frames f32 [N,3,S,S] -> [N*(S/p)^2, Kpad>=3*p*p], column
+ * c*p*p + ky*p + kx ; and the class-token rows  x[n,0,:] = class_emb + pos[0,:]                                */
+int avllm_clip_patchify(const float* frames, void* cols, int32_t N, int32_t S, int32_t p, int32_t Kpad, int32_t dtype,
+                        void* stream);
+int avllm_clip_cls_rows(const void* class_emb, const void* pos, void* x, int32_t N, int32_t tokens, int32_t d,
+                        int32_t dtype, void* stream);
+/* encode()+forward() glue in one pass (clip_whisper_model.py:320-374,426-450,621-707):
+ * virtual sequence X[b] = [prompt_emb[b,0:P] ; fs*a[b,t] + (1-fs)*v[b,t] (zero past each length), t<L]
+ * (a or v may be NULL -> the other alone, scale 1).  out[b,0:S_out] = X (S_out==P+L), AdaptiveAvgPool1d
+ * (P+L > S_out) or linear interpolation align_corners=True (P+L < S_out).                                  */
+int avllm_fuse_pool(const void* a, int32_t Ta, const void* v, int32_t Tv, const void* prompt_emb, int32_t P,
+                    void* out, int32_t B, int32_t L, int32_t S_out, int32_t D, float fusion_scale, int32_t dtype,
+                    void* stream);
+/* clip_grad_norm_ + AdamW (trainer/clip_whisper_trainer.py:457-464,171-232) on a flat fp32 buffer, no host sync:
+ * sumsq accumulates sum(g^2); the step reads it, clips with coef=min(1,max_norm/(sqrt(sumsq)+1e-6)). */
+int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int32_t step, const float* sumsq, float max_norm,
+                     float grad_prescale, void* stream);
+/* build the four padded operand images of one LoRA pair from the fp32 masters A [r,din], B [dout,r]:
+ * A_pad [64,din], AT_pad [din,64] (row stride ld_at), B_pad [dout,64], BT_pad [64,dout] in `dtype` */
+int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,
+                    int64_t ld_at, void* B_pad, void* BT_pad, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------- model level ------------------ */
+
+/* one pre-LN transformer encoder block with biases (Whisper encoder layer / CLIP encoder layer) */
+typedef struct avllm_enc_layer {
+    const void *ln1_w, *ln1_b;
+    const void *wqkv, *bqkv;     /* [3d,d], [3d]  rows = [q;k;v]; whisper k bias = 0 */
+    const void *wo, *bo;
+    const void *ln2_w, *ln2_b;
+    const void *w1, *b1, *w2, *b2;
+} avllm_enc_layer;
+
+typedef struct avllm_whisper {
+    int32_t dtype, d, heads, layers, ffn, n_mels, n_ctx, k1pad;
+    const void *conv1_w, *conv1_b;   /* [d,k1pad] (col c*3+kw, zero padded), [d] */
+    const void *conv2_w, *conv2_b;   /* [d,3d] (col kw*d+c), [d] */
+    const void* pos;                 /* [n_ctx,d] */
+    const avllm_enc_layer* layer;    /* host array [layers] */
+    const void *lnf_w, *lnf_b;
+} avllm_whisper;
+size_t avllm_whisper_workspace_bytes(const avllm_whisper* w, int32_t B);
+/* ClipWhisperModel.encode_audio minus the connector (clip_whisper_model.py:1067-1104 ->
+ * WhisperEncoder.forward): mel f32 [B,80,2*n_ctx] -> out [B,n_ctx,d] */
+int avllm_whisper_encoder_fwd(const avllm_whisper* w, const float* mel, int32_t B, void* out, void* ws,
+                              size_t ws_bytes, void* stream);
+
+typedef struct avllm_clip {
+    int32_t dtype, d, heads, layers, ffn, image, patch, tokens;
+    float eps;
+    const void* patch_w;             /* [d, 3*p*p] */
+    const void *class_emb, *pos;     /* [d], [tokens,d] */
+    const void *pre_ln_w, *pre_ln_b;
+    const avllm_enc_layer* layer;    /* host array [layers] */
+} avllm_clip;
+size_t avllm_clip_workspace_bytes(const avllm_clip* c, int32_t N);
+/* ClipWhisperModel.encode_video minus the connector (clip_whisper_model.py:1108-1142 -> CLIPVisionModel.forward,
+ * last_hidden_state[:,0], no post_layernorm): frames f32 [N,3,S,S] -> cls [N,d] */
+int avllm_clip_vision_cls_fwd(const avllm_clip* c, const float* frames, int32_t N, void* cls, void* ws,
+                              size_t ws_bytes, void* stream);
+
+typedef struct avllm_lora_mod {      /* padded operand images (see avllm_lora_pack); NULL = no adapter */
+    const void *A_pad, *AT_pad, *B_pad, *BT_pad;
+    int64_t ld_at;                   /* row stride of AT_pad: 64, or 192 when q/k/v share one [din,192] image */
+    float *gA, *gB;                  /* fp32 grads [r,din], [dout,r] (accumulated) */
+} avllm_lora_mod;
+
+typedef struct avllm_llama_layer {
+    const void *ln1_w, *ln2_w;
+    const void *wqkv;                /* [3d,d] rows [q;k;v] */
+    const void *wo;                  /* [d,d] */
+    const void *wgu;                 /* [2f,d] rows [gate;up] */
+    const void *wdown;               /* [d,f] */
+    /* transposed images for dX = dY.W (training only; NULL for inference): */
+    const void *wqkv_t;              /* [d,3d] */
+    const void *wo_t;                /* [d,d] */
+    const void *wgu_t;               /* [d,2f] */
+    const void *wdown_t;             /* [f,d] */
+    avllm_lora_mod lora[4];          /* q,k,v,o */
+} avllm_llama_layer;
+
+typedef struct avllm_llama {
+    int32_t dtype, d, heads, layers, ffn, vocab, lora_r;
+    float eps, theta, lora_scale;
+    const void* embed;               /* [vocab,d] */
+    const void* norm_w;
+    const void* lm_head;             /* [vocab,d] */
+    const void* lm_head_t;           /* [d,vocab] (training) */
+    const avllm_llama_layer* layer;  /* host array [layers] */
+} avllm_llama;
+
+size_t avllm_llama_train_workspace_bytes(const avllm_llama* m, int32_t B, int32_t S);
+/* self.llm(inputs_embeds, attention_mask=ones, labels) (clip_whisper_model.py:602-613 ->
+ * LlamaForCausalLM.forward HF:models/llama/modeling_llama.py:435-488 + ForCausalLMLoss).
+ * x [B,S,d]; labels int64 [B,S] with -100 already applied; logits [B,S,vocab] written when non-NULL
+ * (always materialised internally in this version).  loss_sum/count accumulate (zero first); activations for
+ * the backward pass stay in `ws`. */
+int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, const int64_t* labels, int32_t B, int32_t S,
+                              void* logits, float* loss_sum, float* count, void* ws, size_t ws_bytes, void* stream);
+/* loss.backward() for the LoRA tensors only (frozen base weights => dX GEMMs + LoRA dA/dB).
+ * Must follow avllm_llama_lora_fwd_loss with the same ws.  Gradient of  grad_scale * loss_sum / *count.
+ * `after_layer` (may be NULL) is called on the host right after layer i's kernels are enqueued (31 -> 0) so a
+ * data-parallel caller can launch that layer's gradient all-reduce on a side stream. */
+typedef void (*avllm_layer_cb)(int32_t layer, void* user);
+int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels, int32_t B, int32_t S, const float* count,
+                         float grad_scale, void* ws, size_t ws_bytes, avllm_layer_cb after_layer, void* user,
+                         void* stream);
+
+/* Inference: prefill on inputs_embeds and single-token steps with a KV cache (llm.generate,
+ * clip_whisper_model.py:1337-1340 -> GenerationMixin greedy).  kcache/vcache [layers][B][Tmax][d].
+ * prefill writes positions [0,S) and returns the hidden state of the LAST position after the final norm
+ * -> logits_last [B,vocab] f32; decode_step embeds `ids` [B], runs position `pos`, returns logits [B,vocab]. */
+size_t avllm_llama_infer_workspace_bytes(const avllm_llama* m, int32_t B, int32_t S);
+int avllm_llama_prefill(const avllm_llama* m, const void* x, int32_t B, int32_t S, void* kcache, void* vcache,
+                        int32_t Tmax, float* logits_last, void* all_logits, void* ws, size_t ws_bytes, void* stream);
+int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, void* kcache,
+                            void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

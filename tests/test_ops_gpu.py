@@ -1,0 +1,252 @@
+"""Op-level parity: every HIP kernel, called through the C ABI (avllm.ops -> libavllm.so), against the same op in
+plain PyTorch fp32.  fp32 mode must agree to ~1e-5 (exact-fp32 MFMA); bf16 mode to bf16 rounding of the output."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from avllm import lib as L  # noqa: E402
+from avllm import ops  # noqa: E402
+
+
+def rnd(*shape, dtype=torch.float32, dev="cuda", seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(device=dev, dtype=dtype)
+
+
+def close(a, b, atol, rtol, what=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} elements off, max err {err.max().item():.3e} (max ref {b.abs().max().item():.3e})"
+
+
+TOL = {torch.float32: (2e-5, 2e-5), torch.bfloat16: (2e-2, 2e-2)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (1, 64, 64), (300, 768, 768), (257, 8, 128), (2048, 512, 1024)])
+def test_gemm_plain(dev, dtype, M, N, K):
+    A, B = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
+    out = ops.gemm(A, B)
+    ref = A.float() @ B.float().t()
+    at, rt = TOL[dtype]
+    close(out, ref, at * math.sqrt(K), rt, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide §3)."""
+    n = 128
+    A = torch.eye(n, device=dev, dtype=torch.bfloat16)
+    B = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)
+    out = ops.gemm(A, B)                       # = B^T
+    assert torch.equal(out.float(), B.float().t())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue(dev, dtype):
+    M, N, K, K2 = 260, 320, 128, 64
+    A, B = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, seed=4)
+    A2, B2 = rnd(M, K2, dtype=dtype, seed=5), rnd(N, K2, dtype=dtype, seed=6)
+    bias, R = rnd(N, dtype=dtype, seed=7), rnd(M, N, dtype=dtype, seed=8)
+    at, rt = TOL[dtype]
+    for act, fn in ((L.ACT_NONE, lambda x: x), (L.ACT_GELU, lambda x: F.gelu(x)), (L.ACT_QUICK_GELU, lambda x: x * torch.sigmoid(1.702 * x))):
+        out = ops.gemm(A, B, bias=bias, R=R, A2=A2, B2=B2, act=act, alpha=0.5)
+        ref = fn(0.5 * (A.float() @ B.float().t() + A2.float() @ B2.float().t()) + bias.float()) + R.float()
+        close(out, ref, at * 16, rt, f"gemm epilogue act={act}")
+    # broadcast residual rows + output row remap (CLIP patch embedding path) + strided A / f32 output
+    pos = rnd(13, N, dtype=dtype, seed=9)
+    out = torch.zeros((M // 13) * 14, N, device=dev, dtype=dtype)
+    ops.gemm(A, B, out=out, R=pos, r_mod=13, remap=(13, 14, 1), M=(M // 13) * 13)
+    ref = (A.float() @ B.float().t())[: (M // 13) * 13].view(-1, 13, N) + pos.float()
+    close(out.view(-1, 14, N)[:, 1:], ref, at * 16, rt, "gemm remap")
+    assert out.view(-1, 14, N)[:, 0].abs().max().item() == 0
+    big = rnd(M, 3 * K, dtype=dtype, seed=10)
+    o32 = ops.gemm(big[:, K:2 * K], B, out_f32=True)
+    assert o32.dtype == torch.float32
+    close(o32, big[:, K:2 * K].float() @ B.float().t(), at * 16, rt, "gemm strided A")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tn(dev, dtype):
+    M, I, J = 1000, 272, 16
+    P, Q = rnd(M, I, dtype=dtype, seed=11), rnd(M, 64, dtype=dtype, seed=12)
+    out = torch.zeros(I, J, device=dev)
+    ops.gemm_tn(P, Q, out, J=J, alpha=2.0)
+    close(out, 2.0 * P.float().t() @ Q.float()[:, :J], 1e-2, 1e-4, "gemm_tn [I big]")
+    out2 = torch.zeros(J, I, device=dev)
+    ops.gemm_tn(Q, P, out2, I=J)
+    close(out2, Q.float()[:, :J].t() @ P.float(), 1e-2, 1e-4, "gemm_tn [J big]")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [128, 768, 4096])
+def test_norms(dev, dtype, d):
+    x, w, b = rnd(37, d, dtype=dtype, seed=13), rnd(d, dtype=dtype, seed=14, scale=0.1) + 1, rnd(d, dtype=dtype, seed=15, scale=0.1)
+    at, rt = TOL[dtype]
+    close(ops.layernorm(x, w, b, 1e-5), F.layer_norm(x.float(), (d,), w.float(), b.float(), 1e-5), at * 4, rt, "layernorm")
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+    xf = x.float().requires_grad_(True)
+    ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    close(y, ref.detach(), at * 4, rt, "rmsnorm")
+    dy, dres = rnd(37, d, dtype=dtype, seed=16), rnd(37, d, dtype=dtype, seed=17)
+    ref.backward(dy.float())
+    close(ops.rmsnorm_bwd(dy, x, w, rstd, dres), xf.grad + dres.float(), at * 8, rt, "rmsnorm_bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_swiglu(dev, dtype):
+    B, T, H, hd = 2, 19, 3, 128
+    buf = rnd(B * T, 3 * H * hd, dtype=dtype, seed=18)
+    x = buf[:, H * hd: 2 * H * hd]                          # the "k" slice of a fused qkv buffer
+    ref_in = x.float().clone().view(B, T, H, hd)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    ang = (torch.arange(5, 5 + T, device=dev).float()[:, None] * inv[None]).repeat(1, 2)
+    cos, sin = ang.cos()[None, :, None], ang.sin()[None, :, None]
+    rot = torch.cat([-ref_in[..., hd // 2:], ref_in[..., : hd // 2]], -1)
+    ref = ref_in * cos + rot * sin
+    ops.rope_(x, T, H, hd, pos0=5)
+    at, rt = TOL[dtype]
+    close(x.reshape(B, T, H, hd), ref, at * 4, rt, "rope")
+    ops.rope_(x, T, H, hd, pos0=5, inverse=True)
+    close(x.reshape(B, T, H, hd), ref_in, at * 8, rt * 2, "rope inverse")
+    gu = rnd(33, 2 * 192, dtype=dtype, seed=19)
+    g, u = gu.float()[:, :192].requires_grad_(True), gu.float()[:, 192:].requires_grad_(True)
+    h = F.silu(g) * u
+    close(ops.swiglu_fwd(gu), h.detach(), at * 4, rt, "swiglu")
+    dh = rnd(33, 192, dtype=dtype, seed=20)
+    h.backward(dh.float())
+    close(ops.swiglu_bwd(dh, gu), torch.cat([g.grad, u.grad], 1), at * 8, rt, "swiglu_bwd")
+
+
+def _attn_ref(qkv, B, T, H, hd, causal):
+    q, k, v = (t.view(B, T, H, hd).transpose(1, 2) for t in qkv.float().split(H * hd, dim=1))
+    s = q @ k.transpose(-1, -2) * hd ** -0.5
+    if causal:
+        s = s.masked_fill(~torch.ones(T, T, dtype=torch.bool, device=qkv.device).tril(), float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B * T, H * hd), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,H,hd,causal", [(197, 2, 64, False), (1500, 1, 64, False), (256, 2, 128, True), (70, 3, 128, True), (33, 2, 64, True)])
+def test_attention_fwd(dev, dtype, impl, T, H, hd, causal):
+    B = 2
+    qkv = rnd(B * T, 3 * H * hd, dtype=dtype, seed=21)
+    o, lse = ops.attention_fwd(qkv, B, T, H, hd, causal, impl=impl)
+    ro, rl = _attn_ref(qkv, B, T, H, hd, causal)
+    at, rt = TOL[dtype]
+    close(o, ro, at * 2, rt, f"attention impl={impl}")
+    close(lse, rl, 2e-2 if dtype == torch.bfloat16 else 1e-4, 1e-4, "lse")
+
+
+def test_attention_fwd_spike(dev):
+    """Force a late running-max jump (online-softmax rescale path) with a spiked key (cdna guide rule 26)."""
+    B, T, H, hd = 1, 256, 1, 128
+    qkv = rnd(B * T, 3 * hd, dtype=torch.bfloat16, seed=22)
+    qkv[200, hd:2 * hd] = qkv[255, 0:hd] * 8            # key 200 aligned with query 255
+    o, _ = ops.attention_fwd(qkv, B, T, H, hd, True, impl=0)
+    ro, _ = _attn_ref(qkv, B, T, H, hd, True)
+    close(o, ro, 4e-2, 2e-2, "attention spike")
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,H,hd,causal", [(256, 2, 128, True), (70, 2, 128, True), (50, 2, 64, False)])
+def test_attention_bwd(dev, dtype, impl, T, H, hd, causal):
+    B = 2
+    qkv = rnd(B * T, 3 * H * hd, dtype=dtype, seed=23)
+    dout = rnd(B * T, H * hd, dtype=dtype, seed=24)
+    o, lse = ops.attention_fwd(qkv, B, T, H, hd, causal, impl=impl)
+    dqkv = ops.attention_bwd(qkv, o, dout, lse, B, T, H, hd, causal, impl=impl)
+    x = qkv.float().requires_grad_(True)
+    ro, _ = _attn_ref(x, B, T, H, hd, causal)
+    ro.backward(dout.float())
+    at, rt = TOL[dtype]
+    close(dqkv, x.grad, at * 4, rt * 2, f"attention_bwd impl={impl}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_entropy(dev, dtype):
+    B, T, V = 2, 40, 1000
+    logits = rnd(B, T, V, dtype=dtype, seed=25, scale=3.0)
+    labels = torch.randint(0, V, (B, T), device=dev)
+    labels[:, 20:] = -100
+    row_lse, acc = ops.ce_fwd(logits, labels)
+    x = logits.float().requires_grad_(True)
+    shift = torch.cat([labels[:, 1:], torch.full((B, 1), -100, device=dev)], 1)
+    loss = F.cross_entropy(x.view(-1, V), shift.view(-1), ignore_index=-100, reduction="mean")
+    n = (shift != -100).sum().item()
+    assert acc[1].item() == n
+    assert abs(acc[0].item() / n - loss.item()) < 1e-4 * max(1.0, loss.item())
+    loss.backward()
+    dl = ops.ce_bwd(logits, labels, row_lse, acc)
+    close(dl, x.grad, 1e-6 if dtype == torch.float32 else 2e-4, 2e-2 if dtype == torch.bfloat16 else 1e-4, "ce_bwd")
+    am = ops.argmax_rows(logits.view(-1, V))
+    assert torch.equal(am, logits.view(-1, V).float().argmax(-1))
+
+
+def test_adamw_matches_golden(dev, golden_dir):
+    """G5: clip_grad_norm_(0.5) + AdamW(0.9,0.95,wd 0.01) + cosine LR, three steps, vs the torch optimizer."""
+    import numpy as np
+    g5 = np.load(f"{golden_dir}/g5_optimizer.npz")
+    p = torch.tensor(g5["p0"], device=dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(3):
+        g = torch.tensor(g5[f"g{s}"], device=dev)
+        ss = torch.zeros(1, device=dev)
+        ops.grad_sumsq(g, ss)
+        assert abs(ss.sqrt().item() - float(g5[f"norm{s}"])) < 1e-4 * float(g5[f"norm{s}"])
+        ops.adamw_step(p, g, m, v, float(g5[f"lr{s}"]), s + 1, sumsq=ss, max_norm=0.5)
+        close(p, torch.tensor(g5[f"p{s + 1}"], device=dev), 2e-7, 1e-6, f"adamw step {s}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fuse_pool_matches_golden(dev, dtype, golden_dir):
+    """G1 vectors from the reference's _pad_or_truncate/_adaptive_projection (clip_whisper_model.py:320-374,621-707)."""
+    import numpy as np
+    g1 = np.load(f"{golden_dir}/g1_glue.npz")
+    at, rt = TOL[dtype]
+    for key in ("pool_544_256", "pool_1532_256", "pool_300_256", "pool_257_256", "interp_train_100_256", "interp_train_33_256"):
+        src = "_".join(key.replace("interp_train", "interp").split("_")[:3]) + "_in"
+        x = torch.tensor(g1[src], device=dev, dtype=dtype)
+        ref = torch.tensor(g1[key], device=dev)
+        if dtype == torch.bfloat16:      # compare against the same op on the rounded input
+            from oracle import avsr_oracle as O
+            ref = O.adaptive_projection(x.float().cpu(), 256, True).to(dev)
+        out = ops.fuse_pool(x, None, None, x.shape[1], 256, 0.5, x.shape[2], x.shape[0])
+        close(out, ref, at, rt, key)
+    # both modalities + prompt, no pooling: [prompt ; 0.5 a + 0.5 pad(v)] truncated to L
+    a, v, pe = rnd(2, 40, 8, dtype=dtype, seed=30), rnd(2, 7, 8, dtype=dtype, seed=31), rnd(2, 5, 8, dtype=dtype, seed=32)
+    L_ = 24
+    out = ops.fuse_pool(a, v, pe, L_, 5 + L_, 0.5, 8, 2)
+    vp = torch.zeros(2, L_, 8, device=dev)
+    vp[:, :7] = v.float()
+    ref = torch.cat([pe.float(), 0.5 * a.float()[:, :L_] + 0.5 * vp], 1)
+    close(out, ref, at, rt, "fuse")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_im2col_and_embedding(dev, dtype):
+    mel = rnd(2, 80, 200, seed=33)
+    cols = ops.whisper_im2col1(mel, 256, dtype)
+    ref = F.unfold(mel[:, :, None, :], (1, 3), padding=(0, 1)).transpose(1, 2).reshape(2 * 200, 240)     # column c*3+kw
+    close(cols[:, :240], ref, *TOL[dtype], "im2col1")
+    assert cols[:, 240:].abs().max().item() == 0
+    h = rnd(2 * 200, 64, dtype=dtype, seed=34)
+    c2 = ops.whisper_im2col2(h, 2, 200)
+    hp = F.pad(h.float().view(2, 200, 64), (0, 0, 1, 1))
+    ref2 = torch.cat([hp[:, 0:200:2], hp[:, 1:201:2], hp[:, 2:202:2]], -1).reshape(2 * 100, 192)
+    close(c2, ref2, 0, 0, "im2col2")
+    fr = rnd(3, 3, 48, 48, seed=35)
+    pc = ops.clip_patchify(fr, 16, 768, dtype)
+    refp = F.unfold(fr, 16, stride=16).transpose(1, 2).reshape(3 * 9, 768)
+    close(pc, refp, *TOL[dtype], "patchify")
+    table = rnd(50, 32, dtype=dtype, seed=36)
+    ids = torch.randint(0, 50, (2, 9), device=dev)
+    assert torch.equal(ops.embedding(table, ids), table[ids])
