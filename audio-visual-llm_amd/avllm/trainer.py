@@ -1,0 +1,165 @@
+"""ClipWhisperTrainer -- mirror of src/clip_whisper/trainer/clip_whisper_trainer.py:19-1017 for the hot loop
+(`_train_epoch` :412-524, `_process_batch` :604-723, `_setup_optimizer` :171-232, `_validate` :526-603) with the
+same constructor keywords, batch layouts, return dict and output files.  The step is:
+  encoders (HIP) -> fuse/pool (HIP) -> Llama+LoRA fwd+loss (HIP) -> bwd (HIP) [-> RCCL all-reduce, overlapped]
+  -> clip_grad_norm_ + AdamW fused on the flat LoRA buffer (HIP) -> cosine LR.
+No `loss.item()` inside the step: the loss stays on the device and is read once per log interval.
+"""
+from __future__ import annotations
+
+import csv
+import json
+import logging
+import math
+import os
+import time
+
+import torch
+
+from . import ops
+from .dist import LoraGradReducer, is_dist
+
+
+class ClipWhisperTrainer:
+    def __init__(self, model, train_dataloader=None, val_dataloader=None, learning_rate=5e-5, weight_decay=0.01, max_epochs=10,
+                 output_dir="outputs/clip_whisper", device="cuda", fp16=False, grad_accum_steps=1, log_interval=10, save_every=1,
+                 save_steps=None, grad_clip=0.5, warmup_steps=0, log_param_updates=False, total_steps=None):
+        self.model, self.train_dataloader, self.val_dataloader = model, train_dataloader, val_dataloader
+        self.learning_rate, self.weight_decay, self.max_epochs = learning_rate, weight_decay, max_epochs
+        self.output_dir, self.device, self.fp16 = output_dir, device, fp16
+        self.grad_accum_steps = grad_accum_steps           # stored but unused, as in the reference
+        self.log_interval, self.save_every, self.save_steps = log_interval, max(1, save_every or 1), save_steps
+        self.grad_clip, self.warmup_steps = grad_clip, warmup_steps
+        self.global_step = 0
+        self.train_losses, self.val_losses, self.best_val_loss = [], [], float("inf")
+        if total_steps is None:
+            total_steps = max_epochs * (len(train_dataloader) if train_dataloader is not None else 1)
+        self.total_steps = max(1, total_steps)
+        eng = model.llm_engine
+        self.m = torch.zeros_like(eng.lora_p)
+        self.v = torch.zeros_like(eng.lora_p)
+        self.sumsq = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)
+        self.reducer = LoraGradReducer(eng.lora_g, eng.per_layer, eng.cfg.layers)
+
+    # ---- _setup_optimizer :171-232: AdamW(beta 0.9/0.95, eps 1e-8); cosine (with optional linear warmup)
+    def lr_at(self, step):
+        if self.warmup_steps > 0:
+            if step < self.warmup_steps:
+                return self.learning_rate * step / max(1, self.warmup_steps)
+            prog = (step - self.warmup_steps) / max(1, self.total_steps - self.warmup_steps)
+            return self.learning_rate * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+        return self.learning_rate * (1 + math.cos(math.pi * step / self.total_steps)) / 2
+
+    # ---- _process_batch :604-680
+    def _unpack(self, batch):
+        if isinstance(batch, dict):
+            return batch.get("audio"), batch.get("video"), batch.get("labels"), batch.get("prompt")
+        audio, video, texts, labels = batch
+        tok = self.model.tokenizer(texts, return_tensors="pt", padding=True, truncation=True, max_length=self.model.max_seq_len)
+        bs = labels.shape[0]
+        for t in (audio, video):
+            if t is not None and t.shape[0] != bs:
+                raise AssertionError(f"Batch size mismatch: {t.shape[0]} vs labels {bs}")
+        return audio, video, labels, tok.input_ids
+
+    def train_step(self, audio, video, labels, prompt):
+        """One optimizer step on this rank's batch; returns the (global) mean loss as a device scalar."""
+        model, eng = self.model, self.model.llm_engine
+        labels = model._prep_labels(labels)
+        x = model._llm_inputs(audio, video, prompt, S_out=labels.shape[1])
+        eng.fwd_loss(x, labels)
+        acc = self.reducer.reduce_counts(eng.acc)
+        eng.lora_g.zero_()
+        eng.bwd(grad_scale=1.0, count=acc[1:2], after_layer=self.reducer.layer_done if self.reducer.enabled else None)
+        self.reducer.finish()
+        self.sumsq.zero_()
+        ops.grad_sumsq(eng.lora_g, self.sumsq)
+        self.global_step += 1
+        ops.adamw_step(eng.lora_p, eng.lora_g, self.m, self.v, self.lr_at(self.global_step - 1), self.global_step, sumsq=self.sumsq,
+                       max_norm=self.grad_clip or 0.0, wd=self.weight_decay)
+        eng.pack_lora()
+        return acc[0] / acc[1]
+
+    def _train_epoch(self, epoch):
+        self.model.train()
+        total, n, t0 = 0.0, 0, time.time()
+        pending = []
+        for i, batch in enumerate(self.train_dataloader):
+            try:
+                audio, video, labels, prompt = self._unpack(batch)
+                loss = self.train_step(audio, video, labels, prompt)
+            except (ValueError, AssertionError) as e:           # reference swallows per-batch errors (:492-507)
+                logging.error(f"Error in batch {i}: {e}")
+                continue
+            pending.append(loss)
+            if (i + 1) % self.log_interval == 0 or i + 1 == len(self.train_dataloader):
+                vals = torch.stack(pending).float().cpu()
+                pending.clear()
+                ok = vals[torch.isfinite(vals)]
+                total += float(ok.sum()); n += int(ok.numel())
+                logging.info(f"epoch {epoch} batch {i + 1}/{len(self.train_dataloader)} loss {float(vals[-1]):.4f} "
+                             f"avg {total / max(1, n):.4f} lr {self.lr_at(self.global_step):.3e} {(time.time() - t0) / (i + 1):.3f}s/it")
+        return total / max(1, n)
+
+    @torch.no_grad()
+    def _validate(self):
+        if self.val_dataloader is None:
+            return None
+        self.model.eval()
+        tot, cnt = 0.0, 0
+        for batch in self.val_dataloader:
+            audio, video, labels, prompt = self._unpack(batch)
+            out = self.model(audio=audio, video=video, prompt=prompt, labels=labels, return_loss=True)
+            bs = labels.shape[0]
+            v = float(out["loss"])
+            if math.isfinite(v):
+                tot += v * bs; cnt += bs
+        self.model.train()
+        return tot / max(1, cnt)
+
+    def _save_checkpoint(self, epoch, name):
+        """Same keys as trainer:752-760; model_state_dict holds the tensors this build owns (connectors + LoRA)."""
+        if is_dist() and torch.distributed.get_rank() != 0:
+            return
+        os.makedirs(self.output_dir, exist_ok=True)
+        path = os.path.join(self.output_dir, name)
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.global_step},
+                    "scheduler_state_dict": {"step": self.global_step, "total_steps": self.total_steps},
+                    "train_losses": self.train_losses, "val_losses": self.val_losses, "best_val_loss": self.best_val_loss}, path)
+        json.dump({"epoch": epoch, "global_step": self.global_step, "best_val_loss": self.best_val_loss},
+                  open(path.replace(".pt", "_meta.json"), "w"))
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        self.model.load_state_dict(ck["model_state_dict"])
+        o = ck.get("optimizer_state_dict") or {}
+        if "m" in o:
+            self.m.copy_(o["m"]); self.v.copy_(o["v"]); self.global_step = int(o.get("step", 0))
+        self.train_losses, self.val_losses = ck.get("train_losses", []), ck.get("val_losses", [])
+        self.best_val_loss = ck.get("best_val_loss", float("inf"))
+        return ck.get("epoch", 0)
+
+    def train(self):
+        os.makedirs(self.output_dir, exist_ok=True)
+        t0 = time.time()
+        log_csv = os.path.join(self.output_dir, "loss_log.csv")
+        with open(log_csv, "w", newline="") as f:
+            csv.writer(f).writerow(["epoch", "train_loss", "val_loss", "time_hours", "remaining_hours"])
+        for epoch in range(self.max_epochs):
+            tl = self._train_epoch(epoch)
+            vl = self._validate()
+            self.train_losses.append(tl)
+            if vl is not None:
+                self.val_losses.append(vl)
+                if vl < self.best_val_loss:
+                    self.best_val_loss = vl
+                    self._save_checkpoint(epoch, "model_best.pt")
+            if (epoch + 1) % self.save_every == 0:
+                self._save_checkpoint(epoch, f"checkpoint_epoch_{epoch + 1}.pt")
+            el = (time.time() - t0) / 3600
+            with open(log_csv, "a", newline="") as f:
+                csv.writer(f).writerow([epoch + 1, tl, vl, el, el / (epoch + 1) * (self.max_epochs - epoch - 1)])
+        self._save_checkpoint(self.max_epochs - 1, "model_final.pt")
+        return {"train_losses": self.train_losses, "val_losses": self.val_losses, "best_val_loss": self.best_val_loss,
+                "training_hours": (time.time() - t0) / 3600}

