@@ -235,6 +235,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
 
 }  // namespace
 
+bool av_prof_enabled();
+void av_prof_before(hipStream_t st);
+void av_prof_after(hipStream_t st, double flops);
+
 int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     AV_CHECK_ARG(d && d->A && d->B && d->C, "gemm: null operand");
     AV_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -246,6 +250,8 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     e.C = d->C; e.ldc = d->ldc; e.out_f32 = d->out_f32 || d->dtype == AV_F32; e.bias = d->bias; e.R = d->R; e.ldr = d->ldr;
     e.r_mod = d->r_mod; e.g_in = d->g_in; e.g_out = d->g_out; e.g_off = d->g_off;
     e.alpha = d->alpha; e.act = d->act; e.M = d->M; e.N = d->N;
+    const bool prof = av_prof_enabled();
+    if (prof) av_prof_before(st);
     if (d->dtype == AV_BF16) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
@@ -264,6 +270,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         const int tiles = av_cdiv(d->M, FM) * av_cdiv(d->N, FN);
         hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, st, g);
     }
+    if (prof) av_prof_after(st, 2.0 * d->M * (double)d->N * (double)(d->K + d->K2));
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

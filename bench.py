@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- AV-clip train-step throughput of the clip_whisper hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full reference training step (trainer/clip_whisper_trainer.py:433-490) on a batch of synthetic
+LRS3-shaped 5 s clips resident in HBM: Whisper-small encoder + CLIP ViT-B/16 on 125 frames + connectors + fusion +
+adaptive pool to 256 + Llama-2-7B LoRA(r16, q/k/v/o) forward + backward + grad clip + AdamW.  Weights are seeded
+random tensors of the true shapes (no checkpoints offline).  All arithmetic runs in libavllm.so.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement): whole-job samples/s, plus
+  roofline     -- the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / summed HIP-event time, live, vs 2.5 PF/s
+  cpu_baseline -- the CPU oracle timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "audio-visual-llm_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK = 2.5e15       # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+FLOP_PER_CLIP = 11.64e12      # Whisper 0.344 + CLIP 4.391 + connectors 0.010 + LLM fwd 3.417 + bwd 3.451 + LoRA 0.026 TF
+
+
+def synthetic_batch(cfg, B, frames, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    audio = torch.randn(B, 80, 2 * cfg.whisper.n_ctx, generator=g, device=device)
+    u8 = torch.randint(0, 256, (B, frames, 3, cfg.clip.image, cfg.clip.image), generator=g, device=device, dtype=torch.uint8)
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=device).view(1, 1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711], device=device).view(1, 1, 3, 1, 1)
+    video = (u8.float() / 255.0 - mean) / std
+    labels = torch.full((B, 256), 2, dtype=torch.long, device=device)
+    for b in range(B):
+        n = int(torch.randint(8, 41, (1,), generator=g, device=device))
+        labels[b, 0] = 1
+        labels[b, 1:1 + n] = torch.randint(3, cfg.llama.vocab, (n,), generator=g, device=device)
+    return audio, video, labels, labels[:, :32].clone()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=125)
+    ap.add_argument("--max-seq-len", type=int, default=512)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from avllm import lib as L
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    from avllm.trainer import ClipWhisperTrainer
+
+    if args.tiny:
+        cfg = ModelCfg(WhisperCfg(128, 2, 2, 256), ClipCfg(128, 2, 2, 256, 48, 16), LlamaCfg(256, 2, 2, 512, 256), LoraCfg(16, 32.0))
+        model = ClipWhisperModel(device=dev, max_seq_len=args.max_seq_len, config=cfg, precision=args.precision, seed=0)
+        name = "tiny"
+    else:
+        model = ClipWhisperModel("meta-llama/Llama-2-7b-hf", "openai/whisper-small", "openai/clip-vit-base-patch16", device=dev,
+                                 max_seq_len=args.max_seq_len, precision=args.precision, seed=0)
+        name = "whisper-small+clip-vit-b16->llama-2-7b lora r16"
+    cfg = model.cfg
+    model.train()
+    trainer = ClipWhisperTrainer(model, learning_rate=5e-5, weight_decay=0.01, grad_clip=0.5, total_steps=max(1000, args.steps + args.warmup))
+    audio, video, labels, prompt = synthetic_batch(cfg, args.batch, args.frames, 1234 + rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = trainer.train_step(audio, video, labels, prompt)
+    lib = L.load()
+    timing = not args.no_kernel_timing
+    barrier()
+    if timing:
+        L.check(lib.avllm_profile_begin(4000 * args.steps))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(audio, video, labels, prompt)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 4)()
+    if timing:
+        L.check(lib.avllm_profile_end(prof))
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    final_loss = float(loss)
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / dt
+        out = {
+            "metric": "AV-clip train-step samples/sec (clip_whisper -> Llama-2-7B LoRA), whole job",
+            "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {name}, synthetic LRS3-shaped 5 s clips ({args.frames} frames), "
+                                   f"max_seq_len {args.max_seq_len}, train seq 256", "per_gpu_batch": args.batch,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "samples_per_s_per_gpu": round(value / world, 4),
+                       "final_loss": round(final_loss, 5)},
+        }
+        frac_e2e = value / world * FLOP_PER_CLIP / MFMA_BF16_PEAK
+        if timing and prof[2] > 0:
+            ach = prof[1] / (prof[0] * 1e-3) / 1e12           # TFLOP/s over the GEMM launches only
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all dense projections)", "achieved": round(ach, 2),
+                               "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / (MFMA_BF16_PEAK / 1e12), 4),
+                               "traffic": None, "launches_per_step": int(prof[2] / args.steps),
+                               "avg_launch_us": round(1000 * prof[0] / prof[2], 2), "gemm_ms_per_step": round(prof[0] / args.steps, 3),
+                               "gemm_tflop_per_step": round(prof[1] / args.steps / 1e12, 3),
+                               "end_to_end_frac": round(frac_e2e, 4)}
+        else:
+            out["roofline"] = {"bound": "mfma", "achieved": round(value / world * FLOP_PER_CLIP / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
+                               "unit": "TFLOP/s", "frac": round(frac_e2e, 4), "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline.run(frames=args.frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,12 @@ int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,
                     int64_t ld_at, void* B_pad, void* BT_pad, int32_t dtype, void* stream);
 
+/* Live kernel timing for bench.py: between begin and end every avllm_gemm launch (direct or inside the model-level
+ * calls) is bracketed by two HIP events on its stream.  out[0]=sum of GEMM ms, out[1]=sum of algorithmic FLOPs
+ * (2*M*N*(K+K2)), out[2]=launches timed. */
+int avllm_profile_begin(int32_t max_launches);
+int avllm_profile_end(double* out);
+
 /* ---------------------------------------------------------------- model level ------------------ */
 
 /* one pre-LN transformer encoder block with biases (Whisper encoder layer / CLIP encoder layer) */
