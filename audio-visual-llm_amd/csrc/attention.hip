@@ -205,7 +205,7 @@ int av_attention_bwd(const void* q, const void* k, const void* v, const void* o,
     AV_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta_ws, "attention_bwd: null");
     // dO shares O's row stride
     AV_TRY(av_attention_delta(o, dout, delta_ws, B, T, H, hd, ldo, ldo, dtype, st));
-    if (impl == 0 && dtype == AV_BF16 && hd == 128)
+    if (impl == 0 && dtype == AV_BF16 && (hd == 128 || hd == 64))
         return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st);
     return av_attention_bwd_ref(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, st);
 }

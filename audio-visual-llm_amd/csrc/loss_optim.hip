@@ -4,6 +4,9 @@
 #include "common.h"
 #include "avllm_internal.h"
 
+int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
+                    int trans_out, hipStream_t st);
+
 namespace {
 
 template <typename T> struct VecN { static constexpr int n = 4; };
@@ -225,6 +228,10 @@ int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr
 int av_gemm_tn(const void* P, long ldp, int I, const void* Q, long ldq, int J, int M, float* out, long ldo,
                float alpha, int dtype, hipStream_t st) {
     AV_CHECK_ARG(P && Q && out && I > 0 && J > 0 && M > 0, "gemm_tn: bad args");
+    if (dtype == AV_BF16 && ldp % 8 == 0 && ldq % 8 == 0) {
+        if (J <= 16 && I % 128 == 0) return av_gemm_tn_mfma(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, 0, st);
+        if (I <= 16 && J % 128 == 0) return av_gemm_tn_mfma(Q, ldq, J, P, ldp, I, M, out, ldo, alpha, 1, st);
+    }
     int zs = av_cdiv(M, 256);
     zs = zs > 32 ? 32 : zs;
     int mchunk = av_cdiv(M, zs);

@@ -1,0 +1,66 @@
+"""More op-level parity (GPU): special-cased GEMM paths and full-size shapes checked through size-independent
+properties (linearity) or against torch on the same device."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from avllm import ops  # noqa: E402
+from test_ops_gpu import close, rnd  # noqa: E402
+
+
+@pytest.mark.parametrize("M,K", [(2048, 4096), (300, 512), (257, 1024)])
+def test_gemm_skinny_n64(dev, M, K):
+    """N == 64 (LoRA rank side) takes the split-K-in-block kernel."""
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(64, K, dtype=torch.bfloat16, seed=2)
+    out = ops.gemm(A, B, alpha=2.0)
+    close(out, 2.0 * A.float() @ B.float().t(), 0.05 * (K ** 0.5) / 8, 2e-2, "skinny gemm")
+    big = rnd(M, 3 * 64, dtype=torch.bfloat16, seed=3)
+    dst = torch.zeros(M, 192, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A, B, out=dst[:, 64:128])                       # strided destination (column slice)
+    close(dst[:, 64:128], A.float() @ B.float().t(), 0.05 * (K ** 0.5) / 8, 2e-2, "skinny gemm slice")
+    assert dst[:, :64].abs().max().item() == 0 and dst[:, 128:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,NB", [(2048, 4096), (1000, 256), (70, 128)])
+def test_gemm_tn_mfma(dev, M, NB):
+    big = rnd(M, NB, dtype=torch.bfloat16, seed=4)
+    small = rnd(M, 64, dtype=torch.bfloat16, seed=5)
+    out = torch.zeros(NB, 16, device=dev)
+    ops.gemm_tn(big, small, out, J=16, alpha=0.5)
+    ref = 0.5 * big.float().t() @ small.float()[:, :16]
+    close(out, ref, 2e-3 * (M ** 0.5), 1e-3, "gemm_tn mfma [NB,16]")
+    out_t = torch.zeros(16, NB, device=dev)
+    ops.gemm_tn(small, big, out_t, I=16)
+    close(out_t, 2 * ref.t(), 4e-3 * (M ** 0.5), 1e-3, "gemm_tn mfma [16,NB]")
+    ops.gemm_tn(small, big, out_t, I=16)                     # accumulates
+    close(out_t, 4 * ref.t(), 8e-3 * (M ** 0.5), 1e-3, "gemm_tn accumulate")
+
+
+def test_gemm_full_size_llama_shapes(dev):
+    """Llama-2-7B projection shapes at the bench batch (M = 8*256): against torch.matmul on the device."""
+    M = 2048
+    for N, K in ((4096, 4096), (22016, 4096), (4096, 11008), (32000, 4096)):
+        A, B = rnd(M, K, dtype=torch.bfloat16, seed=6), rnd(N, K, dtype=torch.bfloat16, seed=7, scale=K ** -0.5)
+        out = ops.gemm(A, B)
+        ref = (A @ B.t()).float()
+        close(out, ref, 3e-2, 2e-2, f"gemm {M}x{N}x{K}")
+
+
+def test_attention_full_size(dev):
+    """Bench-size attention: Llama (B8,H32,T256,hd128 causal) fwd+bwd, Whisper (T1500) and CLIP (197) fwd vs torch SDPA."""
+    import torch.nn.functional as F
+    for B, T, H, hd, causal, bwd in ((8, 256, 32, 128, True, True), (2, 1500, 12, 64, False, False), (64, 197, 12, 64, False, False)):
+        qkv = rnd(B * T, 3 * H * hd, dtype=torch.bfloat16, seed=8)
+        o, lse = ops.attention_fwd(qkv, B, T, H, hd, causal)
+        x = qkv.float().requires_grad_(bwd)
+        q, k, v = (t.view(B, T, H, hd).transpose(1, 2) for t in x.split(H * hd, dim=1))
+        ref = F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B * T, H * hd)
+        close(o, ref.detach(), 3e-2, 2e-2, f"attention fwd T={T}")
+        if bwd:
+            dout = rnd(B * T, H * hd, dtype=torch.bfloat16, seed=9)
+            ref.backward(dout.float())
+            dqkv = ops.attention_bwd(qkv, o, dout, lse, B, T, H, hd, causal)
+            err = (dqkv.float() - x.grad).pow(2).sum().sqrt() / x.grad.pow(2).sum().sqrt()
+            assert err < 2e-2, err
+            close(dqkv, x.grad, 8e-2, 5e-2, "attention bwd full size")

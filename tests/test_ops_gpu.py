@@ -157,7 +157,7 @@ def test_attention_fwd_spike(dev):
 
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("T,H,hd,causal", [(256, 2, 128, True), (70, 2, 128, True), (50, 2, 64, False)])
+@pytest.mark.parametrize("T,H,hd,causal", [(256, 2, 128, True), (70, 2, 128, True), (50, 2, 64, False), (300, 1, 128, True), (197, 2, 64, False), (130, 1, 128, False)])
 def test_attention_bwd(dev, dtype, impl, T, H, hd, causal):
     B = 2
     qkv = rnd(B * T, 3 * H * hd, dtype=dtype, seed=23)
