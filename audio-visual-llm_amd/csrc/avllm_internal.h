@@ -42,3 +42,5 @@ int av_kv_append(const void* k, const void* v, long ld, void* kc, void* vc, int 
                  int dtype, hipStream_t st);
 int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st);
+int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st);
+int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);

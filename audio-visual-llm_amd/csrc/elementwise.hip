@@ -35,6 +35,43 @@ __global__ void rope_kernel(T* __restrict__ x, long ld, long rows, int T_, int h
     }
 }
 
+// cos/sin table [T][hd/2][2] for positions pos0..pos0+T-1 (computed once per call instead of per element per layer)
+__global__ void rope_table_kernel(float* __restrict__ tab, int T_, int hd, int pos0, float theta) {
+    const int half = hd >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T_ * half) return;
+    const int i = idx % half, t = idx / half;
+    const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)hd);
+    const float ang = (float)(pos0 + t) * inv;
+    tab[2 * idx] = cosf(ang);
+    tab[2 * idx + 1] = sinf(ang);
+}
+
+template <typename T>
+__global__ void rope_tab_kernel(T* __restrict__ x, long ld, long rows, int T_, int heads, int hd, const float* __restrict__ tab, int inverse) {
+    const int half = hd >> 1;
+    const long total = rows * heads * (half >> 2);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int qd = (int)(idx % (half >> 2));
+        const int h = (int)((idx / (half >> 2)) % heads);
+        const long row = idx / ((long)(half >> 2) * heads);
+        const int t = (int)(row % T_);
+        T* p = x + row * ld + (long)h * hd + qd * 4;
+        float a[4], b[4], oa[4], ob[4], cs[8];
+        load_f<4>(p, a);
+        load_f<4>(p + half, b);
+        load_f<8>(tab + ((long)t * half + qd * 4) * 2, cs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float c = cs[2 * j], s = inverse ? -cs[2 * j + 1] : cs[2 * j + 1];
+            oa[j] = a[j] * c - b[j] * s;
+            ob[j] = b[j] * c + a[j] * s;
+        }
+        store_f<4>(p, oa);
+        store_f<4>(p + half, ob);
+    }
+}
+
 // ---------------------------------------------------------------- SwiGLU
 template <typename T>
 __global__ void swiglu_fwd_kernel(const T* __restrict__ gu, T* __restrict__ h, long M, int F) {
@@ -277,6 +314,22 @@ int av_rope(void* x, long ld, long rows, int T, int heads, int hd, int pos0, flo
     const long total = rows * heads * (hd / 8);
     if (dtype == AV_F32) hipLaunchKernelGGL((rope_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (float*)x, ld, rows, T, heads, hd, pos0, theta, inverse);
     else hipLaunchKernelGGL((rope_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, (bf16*)x, ld, rows, T, heads, hd, pos0, theta, inverse);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st) {
+    AV_CHECK_ARG(tab && T > 0 && hd % 8 == 0, "rope_table: bad args");
+    hipLaunchKernelGGL(rope_table_kernel, dim3(av_cdiv((long)T * (hd / 2), 256)), dim3(256), 0, st, tab, T, hd, pos0, theta);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st) {
+    AV_CHECK_ARG(x && tab && rows > 0 && T > 0 && hd % 8 == 0 && ld % 4 == 0, "rope(tab): bad args");
+    const long total = rows * heads * (hd / 8);
+    if (dtype == AV_F32) hipLaunchKernelGGL((rope_tab_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (float*)x, ld, rows, T, heads, hd, tab, inverse);
+    else hipLaunchKernelGGL((rope_tab_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, (bf16*)x, ld, rows, T, heads, hd, tab, inverse);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -115,7 +115,7 @@ struct LlamaTrainWs {
     void** resid;            // host array [layers+1] (lives in a std::vector owned by the caller frame)
     LlamaLayerAct* act;      // host array [layers]
     void *xn2, *hmid, *xf, *logits;
-    float *rstd_f, *row_lse, *delta;
+    float *rstd_f, *row_lse, *delta, *rope_tab;
     // backward scratch
     void *dres, *dxn, *dgu, *dhmid, *dqkv, *datt, *dtqkv, *dto;
 };
@@ -146,6 +146,7 @@ void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs
     w.rstd_f = (float*)b.take((size_t)M * 4);
     w.row_lse = (float*)b.take((size_t)M * 4);
     w.delta = (float*)b.take((size_t)B * m->heads * S * 4);
+    w.rope_tab = (float*)b.take((size_t)S * (d / m->heads) * 4);
     w.dres = b.take((size_t)M * d * es);
     w.dxn = b.take((size_t)M * d * es);
     w.dgu = b.take((size_t)M * 2 * f * es);
@@ -272,6 +273,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     const size_t es = av_dtype_size(dt);
     const int M = B * S;
     AV_HIP(hipMemcpyAsync(resid[0], x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
+    AV_TRY(av_rope_table(w.rope_tab, S, hd, 0, m->theta, st));
     for (int l = 0; l < m->layers; ++l) {
         const avllm_llama_layer& P = m->layer[l];
         LlamaLayerAct& a = act[l];
@@ -281,8 +283,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
                              (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
                              (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));
         }
-        AV_TRY(av_rope(a.qkv, 3 * d, M, S, H, hd, 0, m->theta, 0, dt, st));
-        AV_TRY(av_rope((char*)a.qkv + (size_t)d * es, 3 * d, M, S, H, hd, 0, m->theta, 0, dt, st));
+        AV_TRY(av_rope_tab(a.qkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 0, dt, st));      // q and k slices are adjacent: 2H heads
         const char* qkv = (const char*)a.qkv;
         AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, a.lse, B, S, S, H, hd, 3 * d, 3 * d,
                                 3 * d, d, 1.0f / sqrtf((float)hd), 1, dt, 0, st));
@@ -352,8 +353,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
         AV_TRY(av_attention_bwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, w.datt, a.lse, dqkv, dqkv + (size_t)d * es,
                                 dqkv + (size_t)2 * d * es, w.delta, B, S, H, hd, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                                 1.0f / sqrtf((float)hd), 1, dt, 0, st));
-        AV_TRY(av_rope(dqkv, 3 * d, M, S, H, hd, 0, m->theta, 1, dt, st));
-        AV_TRY(av_rope(dqkv + (size_t)d * es, 3 * d, M, S, H, hd, 0, m->theta, 1, dt, st));
+        AV_TRY(av_rope_tab(dqkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 1, dt, st));
         // ---- q,k,v projections (+LoRA)
         bool any = false, contiguous = true;
         for (int j = 0; j < 3; ++j) {
@@ -384,7 +384,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
 
 // =============================================================================================== Llama inference
 namespace {
-struct LlamaInferWs { void *x, *xn, *qkv, *att, *t, *gu, *hmid, *logits; float* lse; };
+struct LlamaInferWs { void *x, *xn, *qkv, *att, *t, *gu, *hmid, *logits; float* rope_tab; };
 void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs& w, bool all_logits) {
     const size_t es = av_dtype_size(m->dtype);
     const long M = (long)B * S;
@@ -396,6 +396,7 @@ void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs
     w.gu = b.take((size_t)M * 2 * m->ffn * es);
     w.hmid = b.take((size_t)M * m->ffn * es);
     w.logits = b.take((size_t)(all_logits ? M : B) * m->vocab * 4);
+    w.rope_tab = (float*)b.take((size_t)S * (m->d / m->heads) * 4);
 }
 
 // one decoder block on M = B*S rows at positions [pos0, pos0+S); K/V appended to the cache
@@ -410,8 +411,8 @@ int llama_infer_layer(const avllm_llama* m, int l, LlamaInferWs& w, int B, int S
         AV_TRY(lora_proj(m, w.xn, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j], w.t, AVLLM_LORA_PAD,
                          (char*)w.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));
     char* qkv = (char*)w.qkv;
-    AV_TRY(av_rope(qkv, 3 * d, M, S, H, hd, pos0, m->theta, 0, dt, st));
-    AV_TRY(av_rope(qkv + (size_t)d * es, 3 * d, M, S, H, hd, pos0, m->theta, 0, dt, st));
+    if (l == 0) AV_TRY(av_rope_table(w.rope_tab, S, hd, pos0, m->theta, st));
+    AV_TRY(av_rope_tab(qkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 0, dt, st));
     AV_TRY(av_kv_append(qkv + (size_t)d * es, qkv + (size_t)2 * d * es, 3 * d, kcl, vcl, B, S, pos0, Tmax, d, dt, st));
     const float scale = 1.0f / sqrtf((float)hd);
     if (S == 1) {

@@ -17,6 +17,7 @@
 // f32 kernel (strict-parity mode): 64x64x16 tile on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "common.h"
 #include "avllm_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -170,6 +171,262 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16, 256x128 tile, 3-stage ring
+// Large-M variant: 8 waves (4x2, 64x64 each) share a 256x128 tile; a 3-deep LDS ring (3 x 48 KiB) keeps TWO K-tiles of
+// global_load_lds in flight across the single raw s_barrier per K-tile (counted s_waitcnt vmcnt(6), never 0 in the loop),
+// which is what the 2-buffer kernel above cannot do: its __syncthreads drains vmcnt(0) every K-tile.
+constexpr int LBM = 256, LBN = 128;
+constexpr int LSTAGE = (LBM + LBN) * BK * 2;      // 48 KiB
+constexpr int LNSTAGE = 3;
+
+__device__ __forceinline__ void stage_rows8(const bf16* __restrict__ base, long ld, int row0, int rows_max, int k0, char* lds,
+                                            int group, int lane) {
+    // one wave-instruction: 8 rows x 128 B at LDS rows [group*8, group*8+8)
+    const int rsub = lane >> 3;
+    int gr = row0 + group * 8 + rsub;
+    gr = gr < rows_max ? gr : rows_max - 1;
+    const bf16* src = base + (long)gr * ld + k0 + (((lane & 7) ^ rsub) << 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + group * 1024), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_l_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (g.e.M + LBM - 1) / LBM, tiles_n = (g.e.N + LBN - 1) / LBN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * LBM, n0 = tn * LBN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;
+    auto stage = [&](int t, int buf) {
+        char* a_lds = smem + buf * LSTAGE;
+        char* b_lds = a_lds + LBM * BK * 2;
+        const bf16* Ap = t < nt1 ? g.A : g.A2;
+        const bf16* Bp = t < nt1 ? g.B : g.B2;
+        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
+        const int k0 = (t < nt1 ? t : t - nt1) * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) stage_rows8(Ap, la, m0, g.e.M, k0, a_lds, p * 8 + wave, lane);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows8(Bp, lb, n0, g.e.N, k0, b_lds, p * 8 + wave, lane);
+    };
+
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 2 < nt) stage(t + 2, buf >= 1 ? buf - 1 : LNSTAGE - 1);      // (t+2) % 3 == (buf+2) % 3
+        const char* a_lds = smem + buf * LSTAGE;
+        const char* b_lds = a_lds + LBM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xa[4], wb[4];
+            const int chunk = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + fr;
+                xa[i] = *(const bf16x8*)(a_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + fr;
+                wb[j] = *(const bf16x8*)(b_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == LNSTAGE ? 0 : buf + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bf16, 256x128 tile, 4 waves x (128x64)
+// Register-blocked variant.  The 64x64-per-wave kernels above issue one ds_read_b128 per two MFMAs and measure LDS-bound
+// (~0.9 LDS-busy per MFMA cycle at 8 waves/CU).  Here each wave owns 128x64 (8x4 accumulators, 128 AGPRs): 12 fragment reads
+// feed 32 MFMAs.  BK = 32 (64-byte LDS rows, 24 KiB per stage) with a 3-deep ring = 72 KiB, so two workgroups fit per CU and
+// overlap each other's barriers; counted vmcnt(6) keeps two K-tiles of global_load_lds in flight.
+// 64-byte rows need their own swizzle: physical chunk = logical chunk ^ F[(row>>2)&3], F = {0,2,3,1}; with the four
+// ds_read_b128 lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},{32-35,44-47,52-59},{36-43,48-51,60-63} every group then
+// touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+constexpr int WBM = 256, WBN = 128, WBK = 32;
+constexpr int WSTAGE = (WBM + WBN) * WBK * 2;      // 24 KiB
+constexpr int WNSTAGE = 3;
+
+__device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // F = {0,2,3,1}
+
+__device__ __forceinline__ void stage_rows16(const bf16* __restrict__ base, long ld, int row0, int rows_max, int k0, char* lds,
+                                             int group, int lane) {
+    // one wave-instruction: 16 rows x 64 B at LDS rows [group*16, group*16+16)
+    const int rsub = lane >> 2;
+    int gr = row0 + group * 16 + rsub;
+    gr = gr < rows_max ? gr : rows_max - 1;
+    const bf16* src = base + (long)gr * ld + k0 + (((lane & 3) ^ swz64(rsub)) << 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + group * 1024), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_w_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (g.e.M + WBM - 1) / WBM, tiles_n = (g.e.N + WBN - 1) / WBN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * WBM, n0 = tn * WBN;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt1 = g.K / WBK, nt = nt1 + g.K2 / WBK;
+    auto stage = [&](int t, int buf) {
+        char* a_lds = smem + buf * WSTAGE;
+        char* b_lds = a_lds + WBM * WBK * 2;
+        const bf16* Ap = t < nt1 ? g.A : g.A2;
+        const bf16* Bp = t < nt1 ? g.B : g.B2;
+        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
+        const int k0 = (t < nt1 ? t : t - nt1) * WBK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) stage_rows16(Ap, la, m0, g.e.M, k0, a_lds, p * 4 + wave, lane);     // 16 groups = 256 rows
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows16(Bp, lb, n0, g.e.N, k0, b_lds, p * 4 + wave, lane);     // 8 groups = 128 rows
+    };
+
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    const int fr = lane & 15, fq = lane >> 4;
+    // per-lane LDS byte offsets of the fragment rows (row = 16*tile + fr  ->  (row>>2)&3 == (fr>>2))
+    const int frag_off = fr * 64 + ((fq ^ swz64(fr)) << 4);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 2 < nt) stage(t + 2, buf >= 1 ? buf - 1 : WNSTAGE - 1);
+        const char* a_lds = smem + buf * WSTAGE + (wm * 128) * 64 + frag_off;
+        const char* b_lds = smem + buf * WSTAGE + WBM * WBK * 2 + (wn * 64) * 64 + frag_off;
+        bf16x8 wb[4], xa[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(b_lds + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[i] = *(const bf16x8*)(a_lds + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        buf = buf + 1 == WNSTAGE ? 0 : buf + 1;
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + fr;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bf16, 256x256 tile, 8 waves x (128x64)
+// Measured on MI355X (tools/gemm_bench.py): the 128x128 and 256x128 kernels all sit at 0.8-1.0 PFLOP/s whatever their
+// barrier/prefetch structure; what they share is the global->LDS byte rate they need per MFMA cycle (64 resp. 48 B/clk/CU
+// at full MFMA rate against a practical LDS-DMA rate of 30-40 B/clk/CU).  A 256x256 tile needs 32 B/clk/CU.  8 waves (2x4),
+// 128x64 per wave, BK=32, 4-deep ring (4 x 32 KiB = 128 KiB, one workgroup per CU), three K-tiles of LDS-DMA in flight behind
+// a counted vmcnt, one raw barrier per K-tile.
+constexpr int XBM = 256, XBN = 256;
+constexpr int XSTAGE = (XBM + XBN) * WBK * 2;      // 32 KiB
+constexpr int XNSTAGE = 4;
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_x_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_m = (g.e.M + XBM - 1) / XBM, tiles_n = (g.e.N + XBN - 1) / XBN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * XBM, n0 = tn * XBN;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt1 = g.K / WBK, nt = nt1 + g.K2 / WBK;
+    auto stage = [&](int t, int buf) {
+        char* a_lds = smem + buf * XSTAGE;
+        char* b_lds = a_lds + XBM * WBK * 2;
+        const bf16* Ap = t < nt1 ? g.A : g.A2;
+        const bf16* Bp = t < nt1 ? g.B : g.B2;
+        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
+        const int k0 = (t < nt1 ? t : t - nt1) * WBK;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows16(Ap, la, m0, g.e.M, k0, a_lds, p * 8 + wave, lane);     // 16 groups = 256 rows
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows16(Bp, lb, n0, g.e.N, k0, b_lds, p * 8 + wave, lane);
+    };
+
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag_off = fr * 64 + ((fq ^ swz64(fr)) << 4);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int ahead = nt - 1 - t;                      // K-tiles already issued beyond t (capped at 2)
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 3 < nt) stage(t + 3, buf >= 1 ? buf - 1 : XNSTAGE - 1);        // (t+3) % 4 == (buf+3) % 4
+        const char* a_lds = smem + buf * XSTAGE + (wm * 128) * 64 + frag_off;
+        const char* b_lds = smem + buf * XSTAGE + XBM * WBK * 2 + (wn * 64) * 64 + frag_off;
+        bf16x8 wb[4], xa[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(b_lds + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[i] = *(const bf16x8*)(a_lds + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        buf = buf + 1 == XNSTAGE ? 0 : buf + 1;
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + fr;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bf16, N == 64 (LoRA rank side)
 // C[M,64] = alpha * A[M,K] . B[64,K]^T.  A 128x128 tiling leaves 16 workgroups walking K serially (72 us measured at
 // M=2048, K=4096).  Here a workgroup owns 16 rows and splits K over its 8 waves (split-K inside the block, reduced
@@ -305,13 +562,42 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
-        const int tiles = av_cdiv(d->M, BM) * av_cdiv(d->N, BN);
         static bool attr_set = false;
         if (!attr_set) {
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+            AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LNSTAGE * LSTAGE));
             attr_set = true;
         }
-        hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, st, g);
+        static const int variant = getenv("AVLLM_GEMM_VARIANT") ? atoi(getenv("AVLLM_GEMM_VARIANT")) : 0;   // 1 = force 128x128
+        static bool attr2 = false;
+        if (!attr2) {
+            AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNSTAGE * WSTAGE));
+            attr2 = true;
+        }
+        static bool attr3 = false;
+        if (!attr3) {
+            AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XNSTAGE * XSTAGE));
+            attr3 = true;
+        }
+        const int xtiles = av_cdiv(d->M, XBM) * av_cdiv(d->N, XBN);
+        // auto choice from tools/gemm_bench.py on MI355X: 256x256 for very wide N, 256x128/8 waves for very long K, else 128x128
+        const bool auto_x = variant == 0 && d->N >= 16384 && xtiles >= 200;
+        const bool auto_l = variant == 0 && !auto_x && d->K >= 16384;
+        if (d->M > 128 && (variant == 4 || auto_x)) {
+            hipLaunchKernelGGL(gemm_bf16_x_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
+        } else if (d->M > 128 && auto_l) {
+            const int tiles = av_cdiv(d->M, LBM) * av_cdiv(d->N, LBN);
+            hipLaunchKernelGGL(gemm_bf16_l_kernel, dim3(tiles), dim3(512), LNSTAGE * LSTAGE, st, g);
+        } else if (d->M > 128 && variant == 3) {
+            const int tiles = av_cdiv(d->M, WBM) * av_cdiv(d->N, WBN);
+            hipLaunchKernelGGL(gemm_bf16_w_kernel, dim3(tiles), dim3(256), WNSTAGE * WSTAGE, st, g);
+        } else if (d->M > 128 && variant == 2) {
+            const int tiles = av_cdiv(d->M, LBM) * av_cdiv(d->N, LBN);
+            hipLaunchKernelGGL(gemm_bf16_l_kernel, dim3(tiles), dim3(512), LNSTAGE * LSTAGE, st, g);
+        } else {
+            const int tiles = av_cdiv(d->M, BM) * av_cdiv(d->N, BN);
+            hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles), dim3(256), 4 * TILE_BYTES, st, g);
+        }
     } else {
         GemmArgsF g;
         g.A = (const float*)d->A; g.B = (const float*)d->B; g.A2 = (const float*)d->A2; g.B2 = (const float*)d->B2;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark on the shapes of the hot path (random bf16 data).  AVLLM_GEMM_VARIANT=1 forces the 128x128 kernel."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-visual-llm_amd"))
+import torch
+from avllm import ops, lib as L
+
+SHAPES = [  # (M, N, K, tag)
+    (2048, 4096, 4096, "llama q/k/v/o"), (2048, 12288, 4096, "llama qkv fused"), (2048, 22016, 4096, "llama gate+up"),
+    (2048, 4096, 11008, "llama down"), (2048, 4096, 22016, "llama d(gate,up)"), (2048, 11008, 4096, "llama d(down)"),
+    (2048, 32000, 4096, "lm_head"), (4096, 4096, 4096, "llama o B=16"),
+    (197000, 2304, 768, "clip qkv"), (197000, 768, 768, "clip out"), (197000, 3072, 768, "clip fc1"), (197000, 768, 3072, "clip fc2"),
+    (12000, 2304, 768, "whisper qkv"), (12000, 3072, 768, "whisper fc1"), (12000, 768, 3072, "whisper fc2"),
+]
+
+def main():
+    dev = "cuda"
+    act = int(os.environ.get("ACT", "0"))
+    for M, N, K, tag in SHAPES:
+        A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        B = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * K ** -0.5
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        bias = torch.randn(N, device=dev, dtype=torch.bfloat16) if act else None
+        for _ in range(3):
+            ops.gemm(A, B, out=out, bias=bias, act=act)
+        torch.cuda.synchronize()
+        n = 20 if M < 100000 else 8
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            ops.gemm(A, B, out=out, bias=bias, act=act)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print(f"{tag:18s} M={M:6d} N={N:5d} K={K:5d}  {ms*1000:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s", flush=True)
+
+if __name__ == "__main__":
+    main()
