@@ -427,6 +427,84 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16, 256x256 tile, 16 waves x (64x64)
+// tools/ubench/gemm_ablate: at 128x128 the LDS-DMA stream alone (18.8 TB/s chip-wide, ~35 B/clk/CU) takes as long as the
+// ds_read+MFMA phase alone, so the tile is load-bound at ~56 % of MFMA peak.  This variant keeps the per-wave code of the
+// 128x128 kernel (64x64 per wave, its LDS-fed phase sustains ~1.5 PF/s) but lets 16 waves (4x4, 1024 threads, 4 per SIMD)
+// share one 256x256 tile: half the global->LDS bytes per FLOP.  Two 64 KiB stages = 128 KiB LDS, one workgroup per CU.
+constexpr int HBM_ = 256, HBN_ = 256;
+constexpr int HSTAGE = (HBM_ + HBN_) * BK * 2;     // 64 KiB
+
+__global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_m = (g.e.M + HBM_ - 1) / HBM_, tiles_n = (g.e.N + HBN_ - 1) / HBN_;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * HBM_, n0 = tn * HBN_;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;
+    auto stage = [&](int t, int buf) {
+        char* a_lds = smem + buf * HSTAGE;
+        char* b_lds = a_lds + HBM_ * BK * 2;
+        const bf16* Ap = t < nt1 ? g.A : g.A2;
+        const bf16* Bp = t < nt1 ? g.B : g.B2;
+        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
+        const int k0 = (t < nt1 ? t : t - nt1) * BK;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows8(Ap, la, m0, g.e.M, k0, a_lds, p * 16 + wave, lane);     // 32 groups = 256 rows
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows8(Bp, lb, n0, g.e.N, k0, b_lds, p * 16 + wave, lane);
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        const char* a_lds = smem + cur * HSTAGE;
+        const char* b_lds = a_lds + HBM_ * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xa[4], wb[4];
+            const int chunk = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + fr;
+                xa[i] = *(const bf16x8*)(a_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + fr;
+                wb[j] = *(const bf16x8*)(b_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bf16, N == 64 (LoRA rank side)
 // C[M,64] = alpha * A[M,K] . B[64,K]^T.  A 128x128 tiling leaves 16 workgroups walking K serially (72 us measured at
 // M=2048, K=4096).  Here a workgroup owns 16 rows and splits K over its 8 waves (split-K inside the block, reduced
@@ -581,9 +659,17 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         }
         const int xtiles = av_cdiv(d->M, XBM) * av_cdiv(d->N, XBN);
         // auto choice from tools/gemm_bench.py on MI355X: 256x256 for very wide N, 256x128/8 waves for very long K, else 128x128
-        const bool auto_x = variant == 0 && d->N >= 16384 && xtiles >= 200;
-        const bool auto_l = variant == 0 && !auto_x && d->K >= 16384;
-        if (d->M > 128 && (variant == 4 || auto_x)) {
+        const bool auto_h = variant == 0 && xtiles >= 200;          // 256x256 / 16 waves whenever it fills the chip (tools/gemm_bench.py)
+        const bool auto_x = false;
+        const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
+        if (d->M > 128 && (variant == 5 || auto_h)) {
+            static bool attr4 = false;
+            if (!attr4) {
+                AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE));
+                attr4 = true;
+            }
+            hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
+        } else if (d->M > 128 && (variant == 4 || auto_x)) {
             hipLaunchKernelGGL(gemm_bf16_x_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
         } else if (d->M > 128 && auto_l) {
             const int tiles = av_cdiv(d->M, LBM) * av_cdiv(d->N, LBN);

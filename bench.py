@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=125)
     ap.add_argument("--max-seq-len", type=int, default=512)
     ap.add_argument("--precision", default="bf16")
