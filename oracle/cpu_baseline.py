@@ -17,7 +17,8 @@ from . import weights as Wt
 
 def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 4, whisper_layers: int = 2, threads: int | None = None):
     cfg = cfg or Wt.config2()
-    threads = threads or os.cpu_count() or 1
+    # a 1-GPU box's CPU share is 16 cores; more torch threads than that only adds contention
+    threads = threads or min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     t_all = time.time()
     # ---- Whisper: conv stem + `whisper_layers` of the encoder layers, B=1
