@@ -276,9 +276,12 @@ class LlamaEngine:
                                             lm.A_pad, lm.AT_pad, lm.ld_at, lm.B_pad, lm.BT_pad, dt, st))
 
     # ------------------------------------------------------------------ training
-    def fwd_loss(self, x, labels, want_logits=False):
-        """x [B,S,d] (engine dtype), labels int64 [B,S] (-100 applied).  Leaves loss_sum,count in self.acc."""
+    def fwd_loss(self, x, labels, want_logits=False, dropout=0.0, seed=0):
+        """x [B,S,d] (engine dtype), labels int64 [B,S] (-100 applied).  Leaves loss_sum,count in self.acc.
+        `dropout`/`seed`: lora_dropout probability and the step's mask seed (kept in the descriptor for bwd())."""
         lib = L.load()
+        self.desc.lora_dropout = float(dropout) if self.use_lora else 0.0
+        self.desc.dropout_seed = int(seed) & 0xFFFFFFFF
         B, S, _ = x.shape
         x = x.contiguous()
         labels = labels.contiguous()

@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("A2", vp), ("B2", vp), ("C", vp), ("bias", vp), ("R", vp),
                 ("lda", i64), ("ldb", i64), ("lda2", i64), ("ldb2", i64), ("ldc", i64), ("ldr", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("K2", i32), ("dtype", i32), ("out_f32", i32), ("act", i32),
-                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32)]
+                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32)]
 
 
 class EncLayer(C.Structure):
@@ -56,7 +56,7 @@ class LlamaLayer(C.Structure):
 
 class Llama(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "vocab", "lora_r")] + \
-               [(n, f32) for n in ("eps", "theta", "lora_scale")] + \
+               [(n, f32) for n in ("eps", "theta", "lora_scale", "lora_dropout")] + [("dropout_seed", C.c_uint32)] + \
                [(n, vp) for n in ("embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))]
 
 
@@ -79,6 +79,7 @@ _SIGS = {
     "avllm_argmax_rows": ([vp, i64, i64, i32, vp, i32, vp], i32),
     "avllm_embedding": ([vp, vp, vp, i64, i32, i32, vp], i32),
     "avllm_cast": ([vp, i32, vp, i32, i64, vp], i32),
+    "avllm_dropout": ([vp, vp, i64, i32, C.c_uint32, f32, i32, vp], i32),
     "avllm_whisper_im2col1": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "avllm_whisper_im2col2": ([vp, vp, i32, i32, i32, i32, vp], i32),
     "avllm_clip_patchify": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),

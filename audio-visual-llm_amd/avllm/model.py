@@ -65,8 +65,7 @@ class ClipWhisperModel:
         precision = precision or ("bf16" if use_fp16 else "fp32")
         self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
         self.training = True
-        if lora_dropout and use_lora:
-            logging.info("lora_dropout=%.3f requested; this build applies the adapters without dropout (DESIGN.md)", lora_dropout)
+        self._drop_step = 0
 
         cfg, W = resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lora_r, lora_alpha, use_lora,
                               _provided_llm, _provided_whisper, _provided_clip, device, self.dtype)
@@ -239,6 +238,13 @@ class ClipWhisperModel:
         return x, torch.ones(x.shape[0], x.shape[1], dtype=torch.long, device=x.device)
 
     # ------------------------------------------------------------------ forward / loss
+    def _dropout_args(self):
+        """lora_dropout is active in train() mode only; every training forward draws a fresh mask seed."""
+        if not (self.training and self.use_lora and self.lora_dropout):
+            return {"dropout": 0.0, "seed": 0}
+        self._drop_step += 1
+        return {"dropout": float(self.lora_dropout), "seed": (self._drop_step * 0x9E3779B1 + 12345) & 0xFFFFFFFF}
+
     def _prep_labels(self, labels):
         if isinstance(labels, list):
             if all(isinstance(t, torch.Tensor) for t in labels):
@@ -261,7 +267,7 @@ class ClipWhisperModel:
             labels = None
         if self.training and labels is not None:
             x = self._llm_inputs(audio, video, prompt, S_out=labels.shape[1])       # adaptive pool / interpolate (:577-585)
-            logits = self.llm_engine.fwd_loss(x, labels, want_logits=True)
+            logits = self.llm_engine.fwd_loss(x, labels, want_logits=True, **self._dropout_args())
             acc = self.llm_engine.acc
             loss = acc[0] / acc[1]
             if self.lora_param is not None and self.lora_param.requires_grad:

@@ -199,3 +199,11 @@ def clip_patchify(frames, patch, Kpad, dtype):
     cols = torch.empty(N * g * g, Kpad, device=frames.device, dtype=dtype)
     L.check(L.load().avllm_clip_patchify(L.ptr(frames), L.ptr(cols), N, S, patch, Kpad, L.dt_of(cols), L.stream_ptr()))
     return cols
+
+
+def dropout(x, seed, p):
+    """y = x * keep/(1-p) with the library's counter-based mask (avllm_dropout)."""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().avllm_dropout(L.ptr(x), L.ptr(y), x.numel() // x.shape[-1], x.shape[-1], seed & 0xFFFFFFFF, p, L.dt_of(x), L.stream_ptr()))
+    return y

@@ -67,7 +67,7 @@ class ClipWhisperTrainer:
         model, eng = self.model, self.model.llm_engine
         labels = model._prep_labels(labels)
         x = model._llm_inputs(audio, video, prompt, S_out=labels.shape[1])
-        eng.fwd_loss(x, labels)
+        eng.fwd_loss(x, labels, **model._dropout_args())
         acc = self.reducer.reduce_counts(eng.acc)
         eng.lora_g.zero_()
         eng.bwd(grad_scale=1.0, count=acc[1:2], after_layer=self.reducer.layer_done if self.reducer.enabled else None)

@@ -50,6 +50,7 @@ int avllm_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const fl
 int avllm_argmax_rows(const void* logits, int64_t ld, int64_t rows, int32_t V, int64_t* out, int32_t dtype, void* stream) { return av_argmax_rows(logits, ld, rows, V, out, dtype, ST); }
 int avllm_embedding(const void* table, const int64_t* ids, void* out, int64_t n, int32_t d, int32_t dtype, void* stream) { return av_embedding(table, ids, out, n, d, dtype, ST); }
 int avllm_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int64_t n, void* stream) { return av_cast(src, sdt, dst, ddt, n, ST); }
+int avllm_dropout(const void* x, void* y, int64_t rows, int32_t d, uint32_t seed, float p, int32_t dtype, void* stream) { return av_dropout(x, y, rows, d, seed, p, dtype, ST); }
 int avllm_whisper_im2col1(const float* mel, void* cols, int32_t B, int32_t n_mels, int32_t T, int32_t Kpad, int32_t dtype, void* stream) { return av_whisper_im2col1(mel, cols, B, n_mels, T, Kpad, dtype, ST); }
 int avllm_whisper_im2col2(const void* h, void* cols, int32_t B, int32_t T, int32_t d, int32_t dtype, void* stream) { return av_whisper_im2col2(h, cols, B, T, d, dtype, ST); }
 int avllm_clip_patchify(const float* frames, void* cols, int32_t N, int32_t S, int32_t p, int32_t Kpad, int32_t dtype, void* stream) { return av_clip_patchify(frames, cols, N, S, p, Kpad, dtype, ST); }

@@ -44,3 +44,4 @@ int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st);
 int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st);
 int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);
+int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st);

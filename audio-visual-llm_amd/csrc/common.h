@@ -133,4 +133,15 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
+// Counter-based dropout mask: keep(seed, index) is a pure function, so forward and backward regenerate the same mask
+// instead of storing it.  32-bit avalanche hash (lowbias32) of the element index mixed with the seed.
+__host__ __device__ __forceinline__ uint32_t av_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool av_keep(uint32_t seed, unsigned long long idx, float p) {
+    const uint32_t h = av_hash32((uint32_t)idx ^ av_hash32(seed + (uint32_t)(idx >> 32) * 0x9E3779B9U));
+    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
 static inline int av_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -109,6 +109,20 @@ __global__ void swiglu_bwd_kernel(const T* __restrict__ dh, const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- dropout (counter-based mask, common.h av_keep)
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int d, uint32_t seed, float p) {
+    const long total = rows * (d >> 2);
+    const float sc = 1.0f / (1.0f - p);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        load_f<4>(x + idx * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = av_keep(seed, (unsigned long long)(idx * 4 + j), p) ? v[j] * sc : 0.f;
+        store_f<4>(y + idx * 4, v);
+    }
+}
+
 // ---------------------------------------------------------------- embedding / cast
 template <typename T>
 __global__ void embedding_kernel(const T* __restrict__ table, const int64_t* __restrict__ ids, T* __restrict__ out, long n, int d) {
@@ -346,6 +360,15 @@ int av_swiglu_bwd(const void* dh, const void* gu, void* dgu, long M, int F, int 
     AV_CHECK_ARG(dh && gu && dgu && M > 0 && F % 4 == 0, "swiglu_bwd: bad args");
     if (dtype == AV_F32) hipLaunchKernelGGL((swiglu_bwd_kernel<float>), dim3(grid_for(M * (F / 4))), dim3(256), 0, st, (const float*)dh, (const float*)gu, (float*)dgu, M, F);
     else hipLaunchKernelGGL((swiglu_bwd_kernel<bf16>), dim3(grid_for(M * (F / 4))), dim3(256), 0, st, (const bf16*)dh, (const bf16*)gu, (bf16*)dgu, M, F);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st) {
+    AV_CHECK_ARG(x && y && rows > 0 && d % 4 == 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+    const long total = rows * (d / 4);
+    if (dtype == AV_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)y, rows, d, seed, p);
+    else hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, rows, d, seed, p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

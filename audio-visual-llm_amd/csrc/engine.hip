@@ -114,7 +114,7 @@ struct LlamaLayerAct {
 struct LlamaTrainWs {
     void** resid;            // host array [layers+1] (lives in a std::vector owned by the caller frame)
     LlamaLayerAct* act;      // host array [layers]
-    void *xn2, *hmid, *xf, *logits;
+    void *xn2, *hmid, *xf, *logits, *xd;
     float *rstd_f, *row_lse, *delta, *rope_tab;
     // backward scratch
     void *dres, *dxn, *dgu, *dhmid, *dqkv, *datt, *dtqkv, *dto;
@@ -143,6 +143,7 @@ void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs
     w.hmid = b.take((size_t)M * f * es);
     w.xf = b.take((size_t)M * d * es);
     w.logits = b.take((size_t)M * m->vocab * es);
+    w.xd = b.take((size_t)M * d * es);
     w.rstd_f = (float*)b.take((size_t)M * 4);
     w.row_lse = (float*)b.take((size_t)M * 4);
     w.delta = (float*)b.take((size_t)B * m->heads * S * 4);
@@ -166,11 +167,12 @@ int check_llama(const avllm_llama* m) {
 
 // y[:, slice j] = x W_j^T (+ t_j B_j^T)
 int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long ldw, int K, int N, const avllm_lora_mod& lm,
-              void* t, long ldt, void* y, long ldy, const void* R, long ldr, int M, hipStream_t st) {
+              void* t, long ldt, void* y, long ldy, const void* R, long ldr, int M, hipStream_t st, const void* xl = nullptr) {
     avllm_gemm_desc g;
     const bool has = lm.A_pad != nullptr;
     if (has) {
-        g = gemm_desc(m->dtype, x, ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
+        // xl = dropout(x) for the adapter branch when lora_dropout is active (peft: lora_B(lora_A(dropout(x))))
+        g = gemm_desc(m->dtype, xl ? xl : x, xl ? (long)K : ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
         g.alpha = m->lora_scale;
         AV_TRY(av_gemm(&g, st));
     }
@@ -274,20 +276,27 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     const int M = B * S;
     AV_HIP(hipMemcpyAsync(resid[0], x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
     AV_TRY(av_rope_table(w.rope_tab, S, hd, 0, m->theta, st));
+    const bool drop = m->lora_dropout > 0.f;
     for (int l = 0; l < m->layers; ++l) {
         const avllm_llama_layer& P = m->layer[l];
         LlamaLayerAct& a = act[l];
         AV_TRY(av_rmsnorm_fwd(resid[l], P.ln1_w, a.xn1, a.rstd1, M, d, m->eps, dt, st));
         for (int j = 0; j < 3; ++j) {
+            const void* xl = nullptr;
+            if (drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xl = w.xd; }
             AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j],
                              (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
-                             (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));
+                             (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st, xl));
         }
         AV_TRY(av_rope_tab(a.qkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 0, dt, st));      // q and k slices are adjacent: 2H heads
         const char* qkv = (const char*)a.qkv;
         AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, a.lse, B, S, S, H, hd, 3 * d, 3 * d,
                                 3 * d, d, 1.0f / sqrtf((float)hd), 1, dt, 0, st));
-        AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st));
+        {
+            const void* xl = nullptr;
+            if (drop && P.lora[3].A_pad) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xl = w.xd; }
+            AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st, xl));
+        }
         AV_TRY(av_rmsnorm_fwd(a.h1, P.ln2_w, w.xn2, a.rstd2, M, d, m->eps, dt, st));
         avllm_gemm_desc g = gemm_desc(dt, w.xn2, d, P.wgu, d, a.gu, 2 * f, M, 2 * f, d);
         AV_TRY(av_gemm(&g, st));
@@ -319,6 +328,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
     const size_t es = av_dtype_size(dt);
     const int M = B * S, R = m->lora_r;
     const float sc = m->lora_scale;
+    const bool drop = m->lora_dropout > 0.f;
     AV_TRY(av_ce_bwd(w.logits, V, labels, w.row_lse, count, grad_scale, w.logits, B, S, V, dt, st));
     avllm_gemm_desc g = gemm_desc(dt, w.logits, V, m->lm_head_t, V, w.dxn, d, M, d, V);
     AV_CHECK_ARG(V % 64 == 0, "llama_lora_bwd: vocab %d must be a multiple of 64", V);
@@ -343,10 +353,17 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             avllm_gemm_desc gt = gemm_desc(dt, w.dres, d, lo.BT_pad, d, w.dto, AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, d);
             gt.alpha = sc;
             AV_TRY(av_gemm(&gt, st));
-            AV_TRY(av_gemm_tn(w.dto, AVLLM_LORA_PAD, R, a.att, d, d, M, lo.gA, d, 1.0f, dt, st));
-            g.A2 = w.dto; g.lda2 = AVLLM_LORA_PAD; g.B2 = lo.AT_pad; g.ldb2 = lo.ld_at; g.K2 = AVLLM_LORA_PAD;
+            const void* xin = a.att;
+            if (drop) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xin = w.xd; }
+            AV_TRY(av_gemm_tn(w.dto, AVLLM_LORA_PAD, R, xin, d, d, M, lo.gA, d, 1.0f, dt, st));
+            if (!drop) { g.A2 = w.dto; g.lda2 = AVLLM_LORA_PAD; g.B2 = lo.AT_pad; g.ldb2 = lo.ld_at; g.K2 = AVLLM_LORA_PAD; }
         }
         AV_TRY(av_gemm(&g, st));
+        if (lo.A_pad && drop) {       // d att += mask_o * (dto . A_o) / (1-p): the adapter's input gradient passes back through its dropout
+            avllm_gemm_desc gm = gemm_desc(dt, w.dto, AVLLM_LORA_PAD, lo.AT_pad, lo.ld_at, w.datt, d, M, d, AVLLM_LORA_PAD);
+            gm.R = w.datt; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + 3; gm.drop_p = m->lora_dropout;
+            AV_TRY(av_gemm(&gm, st));
+        }
         // ---- attention
         const char* qkv = (const char*)a.qkv;
         char* dqkv = (char*)w.dqkv;
@@ -366,15 +383,27 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             avllm_gemm_desc gt = gemm_desc(dt, dy, 3 * d, lj.BT_pad, d, dtj, 3 * AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, d);
             gt.alpha = sc;
             AV_TRY(av_gemm(&gt, st));
-            AV_TRY(av_gemm_tn(dtj, 3 * AVLLM_LORA_PAD, R, a.xn1, d, d, M, lj.gA, d, 1.0f, dt, st));
+            const void* xin = a.xn1;
+            if (drop) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xin = w.xd; }
+            AV_TRY(av_gemm_tn(dtj, 3 * AVLLM_LORA_PAD, R, xin, d, d, M, lj.gA, d, 1.0f, dt, st));
             if (lj.ld_at != 3 * AVLLM_LORA_PAD ||
                 (const char*)lj.AT_pad != (const char*)P.lora[0].AT_pad + (size_t)j * AVLLM_LORA_PAD * es) contiguous = false;
         }
         if (l > 0) {      // d(inputs_embeds) is not needed: encoders/connectors are frozen
-            AV_CHECK_ARG(!any || contiguous, "llama_lora_bwd: q/k/v AT_pad images must be the three 64-column slices of one [d,192] matrix");
+            AV_CHECK_ARG(!any || contiguous || drop, "llama_lora_bwd: q/k/v AT_pad images must be the three 64-column slices of one [d,192] matrix");
             g = gemm_desc(dt, w.dqkv, 3 * d, P.wqkv_t, 3 * d, w.dxn, d, M, d, 3 * d);
-            if (any) { g.A2 = w.dtqkv; g.lda2 = 3 * AVLLM_LORA_PAD; g.B2 = P.lora[0].AT_pad; g.ldb2 = 3 * AVLLM_LORA_PAD; g.K2 = 3 * AVLLM_LORA_PAD; }
+            if (any && !drop) { g.A2 = w.dtqkv; g.lda2 = 3 * AVLLM_LORA_PAD; g.B2 = P.lora[0].AT_pad; g.ldb2 = 3 * AVLLM_LORA_PAD; g.K2 = 3 * AVLLM_LORA_PAD; }
             AV_TRY(av_gemm(&g, st));
+            if (any && drop) {
+                for (int j = 0; j < 3; ++j) {
+                    const avllm_lora_mod& lj = P.lora[j];
+                    if (!lj.A_pad) continue;
+                    avllm_gemm_desc gm = gemm_desc(dt, (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD, lj.AT_pad, lj.ld_at,
+                                                   w.dxn, d, M, d, AVLLM_LORA_PAD);
+                    gm.R = w.dxn; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + j; gm.drop_p = m->lora_dropout;
+                    AV_TRY(av_gemm(&gm, st));
+                }
+            }
             AV_TRY(av_rmsnorm_bwd(w.dxn, resid[l], P.ln1_w, a.rstd1, w.dres, w.dres, M, d, dt, st));
         }
         if (after_layer) after_layer(l, user);

@@ -27,6 +27,7 @@ struct EpiParams {
     int g_in, g_out, g_off;
     float alpha; int act;
     int M, N;
+    uint32_t drop_seed; float drop_p;
 };
 
 // v[4] = 4 consecutive output columns n0..n0+3 of logical row m
@@ -41,6 +42,11 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& e, int m, int n
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i] * e.alpha + b[i], e.act);
+    if (e.drop_p > 0.f) {
+        const float sc = 1.0f / (1.0f - e.drop_p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = av_keep(e.drop_seed, (unsigned long long)m * e.N + n0 + i, e.drop_p) ? v[i] * sc : 0.f;
+    }
     if (e.R) {
         const long rr = e.r_mod > 0 ? (m % e.r_mod) : m;
         const T* rp = (const T*)e.R + rr * e.ldr + n0;
@@ -630,9 +636,10 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     e.C = d->C; e.ldc = d->ldc; e.out_f32 = d->out_f32 || d->dtype == AV_F32; e.bias = d->bias; e.R = d->R; e.ldr = d->ldr;
     e.r_mod = d->r_mod; e.g_in = d->g_in; e.g_out = d->g_out; e.g_off = d->g_off;
     e.alpha = d->alpha; e.act = d->act; e.M = d->M; e.N = d->N;
+    e.drop_seed = d->drop_seed; e.drop_p = d->drop_p;
     const bool prof = av_prof_enabled();
     if (prof) av_prof_before(st);
-    if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 &&
+    if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
         d->K % (32 * SK_WAVES) == 0 && d->M >= 256) {
         hipLaunchKernelGGL(gemm_skinny64_kernel, dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
                            (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32);

@@ -50,6 +50,8 @@ typedef struct avllm_gemm_desc {
     float alpha;
     int32_t r_mod;                      /* >0: residual row = m % r_mod (broadcast position embeddings) */
     int32_t g_in, g_out, g_off;         /* g_in>0: output row = (m/g_in)*g_out + g_off + m%g_in */
+    uint32_t drop_seed;                 /* drop_p>0: the product (before +R) is multiplied by the dropout mask */
+    float drop_p;                       /*   keep(drop_seed, m*N+n, p)/(1-p)  -- see avllm_dropout */
 } avllm_gemm_desc;
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
 
@@ -95,6 +97,9 @@ int avllm_argmax_rows(const void* logits, int64_t ld, int64_t rows, int32_t V, i
 /* out[i,:] = table[ids[i],:] ; llm.get_input_embeddings() (clip_whisper_model.py:464-487) */
 int avllm_embedding(const void* table, const int64_t* ids, void* out, int64_t n, int32_t d, int32_t dtype, void* stream);
 int avllm_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
+/* nn.Dropout(p) of peft's lora.Linear (lora_dropout, clip_whisper_model.py:973-982): y = x * keep / (1-p) with the
+ * counter-based mask keep(seed, row*d+col, p) (csrc/common.h av_keep); the same (seed,p) regenerates the same mask. */
+int avllm_dropout(const void* x, void* y, int64_t rows, int32_t d, uint32_t seed, float p, int32_t dtype, void* stream);
 
 /* Whisper conv stem im2col (HF:models/whisper/modeling_whisper.py:618-619).
  * conv1: mel f32 [B,80,T] -> cols [B*T, Kpad] with column c*3+kw = mel[b,c,t+kw-1] (zero padded, Kpad>=240)
@@ -194,6 +199,8 @@ typedef struct avllm_llama_layer {
 typedef struct avllm_llama {
     int32_t dtype, d, heads, layers, ffn, vocab, lora_r;
     float eps, theta, lora_scale;
+    float lora_dropout;              /* applied by avllm_llama_lora_fwd_loss/_bwd only (training); 0 = off */
+    uint32_t dropout_seed;           /* module j of layer l uses seed dropout_seed + 4*l + j; change it every step */
     const void* embed;               /* [vocab,d] */
     const void* norm_w;
     const void* lm_head;             /* [vocab,d] */

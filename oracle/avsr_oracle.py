@@ -209,16 +209,18 @@ def apply_rope(x, cos, sin):
     return x * cos + rot * sin
 
 
-def lora_linear(x, w, lora, key, scale):
-    """peft lora.Linear (dropout=identity here): W x + scale * B(A x).  Reference wrap:
-    clip_whisper_model.py:961-1005.  Parity unpinned against real peft (not installed)."""
+def lora_linear(x, w, lora, key, scale, masks=None):
+    """peft lora.Linear: W x + scale * B(A dropout(x)).  `masks[key]` (same shape as x, already scaled by 1/(1-p)) is the
+    dropout mask of this module; None = eval / p=0.  Reference wrap: clip_whisper_model.py:961-1005.
+    Parity unpinned against real peft (not installed)."""
     y = x @ w.T
     if lora is not None and (key + ".lora_A") in lora:
-        y = y + scale * ((x @ lora[key + ".lora_A"].T) @ lora[key + ".lora_B"].T)
+        xl = x * masks[key].view_as(x) if masks is not None and key in masks else x
+        y = y + scale * ((xl @ lora[key + ".lora_A"].T) @ lora[key + ".lora_B"].T)
     return y
 
 
-def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0):
+def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0, masks=None):
     """LlamaModel.forward, HF:models/llama/modeling_llama.py:366-419; layer :284-324; attn :236-281.
     x [B,T,d] inputs_embeds.  `past` = optional list of (k,v) per layer (KV cache), updated in place."""
     B, T, d = x.shape
@@ -229,9 +231,9 @@ def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0):
         L = f"model.layers.{i}."
         K = f"layers.{i}."
         h = rms_norm(x, sd[L + "input_layernorm.weight"], c.eps)
-        q = lora_linear(h, sd[L + "self_attn.q_proj.weight"], lora, K + "q_proj", scale)
-        k = lora_linear(h, sd[L + "self_attn.k_proj.weight"], lora, K + "k_proj", scale)
-        v = lora_linear(h, sd[L + "self_attn.v_proj.weight"], lora, K + "v_proj", scale)
+        q = lora_linear(h, sd[L + "self_attn.q_proj.weight"], lora, K + "q_proj", scale, masks)
+        k = lora_linear(h, sd[L + "self_attn.k_proj.weight"], lora, K + "k_proj", scale, masks)
+        v = lora_linear(h, sd[L + "self_attn.v_proj.weight"], lora, K + "v_proj", scale, masks)
         sp = lambda t: t.view(B, T, H, hd).transpose(1, 2)
         q, k, v = apply_rope(sp(q), cos, sin), apply_rope(sp(k), cos, sin), sp(v)
         if past is not None:
@@ -240,7 +242,7 @@ def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0):
                 v = torch.cat([past[i][1], v], dim=2)
             past[i] = (k, v)
         a = softmax_attention(q, k, v, hd ** -0.5, causal=True)
-        x = x + lora_linear(a, sd[L + "self_attn.o_proj.weight"], lora, K + "o_proj", scale)
+        x = x + lora_linear(a, sd[L + "self_attn.o_proj.weight"], lora, K + "o_proj", scale, masks)
         h = rms_norm(x, sd[L + "post_attention_layernorm.weight"], c.eps)
         g = h @ sd[L + "mlp.gate_proj.weight"].T
         u = h @ sd[L + "mlp.up_proj.weight"].T
@@ -285,14 +287,14 @@ def forward(W, cfg, audio=None, video=None, prompt=None, labels=None, training=T
     return out
 
 
-def train_step_grads(W, cfg, audio, video, prompt, labels):
+def train_step_grads(W, cfg, audio, video, prompt, labels, masks=None):
     """One forward+backward of the reference's training step (trainer/clip_whisper_trainer.py:433-456)
     with freeze_encoders=True: encoders+connectors run under no_grad (clip_whisper_model.py:1096-1106),
     so only the LoRA tensors receive gradients."""
     with torch.no_grad():
         x, mask, lab = prepare_llm_inputs(W, cfg, audio, video, prompt, labels, training=True)
     lora = {k: v.clone().requires_grad_(True) for k, v in W["lora"].items()}
-    h = llama_hidden(W["llama"], lora, cfg.llama, cfg.lora, x)
+    h = llama_hidden(W["llama"], lora, cfg.llama, cfg.lora, x, masks=masks)
     logits = h @ W["llama"]["lm_head.weight"].T
     loss = causal_lm_loss(logits, lab)
     loss.backward()

@@ -196,3 +196,40 @@ def test_state_dict_roundtrip(dev, tiny, model32, tmp_path):
     for k, v in m2.state_dict().items():
         if "connector" in k or "lora" in k:
             assert torch.equal(v.cpu(), sd[k].cpu()), k
+
+
+def test_lora_dropout_matches_oracle_with_same_masks(dev, tiny):
+    """lora_dropout>0 (peft: lora_B(lora_A(dropout(x)))): the library regenerates its counter-based masks in forward and
+    backward; the oracle is given the SAME masks (extracted with avllm_dropout on ones) and must agree on loss and grads."""
+    from avllm import ops
+    g, oc, W, audio, video, labels, prompt = tiny
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    p = 0.25
+    m = ClipWhisperModel(device="cuda:0", lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=p, max_seq_len=512, config=cfg, weights=W,
+                         precision="fp32").train()
+    out = m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    m.lora_param.grad = None
+    out["loss"].backward()
+    seed = m.llm_engine.desc.dropout_seed
+    assert m.llm_engine.desc.lora_dropout == pytest.approx(p)
+    ones = torch.ones(2 * 256, oc.llama.hidden, device=dev)
+    masks = {}
+    for l in range(oc.llama.layers):
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj", "o_proj")):
+            mk = ops.dropout(ones, seed + 4 * l + j, p).cpu().view(2, 256, -1)
+            keep = (mk > 0).float().mean().item()
+            assert abs(keep - (1 - p)) < 0.02, keep
+            masks[f"layers.{l}.{nm}"] = mk
+    assert not torch.equal(masks["layers.0.q_proj"], masks["layers.0.k_proj"])        # independent masks per module
+    ol, ologits, og = O.train_step_grads(W, oc, audio, video, prompt, labels, masks=masks)
+    assert abs(float(out["loss"].detach()) - float(ol)) < 1e-4
+    assert (out["logits"].float().cpu() - ologits).abs().max() < 1e-3
+    gv = m.llm_engine.lora_views(m.lora_param.grad)
+    for k, gr in gv.items():
+        assert (gr.cpu() - og[k]).abs().max() <= 2e-4 * max(1e-3, float(og[k].abs().max())) + 1e-7, k
+    # a second training forward draws a different mask; eval() disables dropout
+    m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    assert m.llm_engine.desc.dropout_seed != seed
+    assert m.eval()._dropout_args()["dropout"] == 0.0
