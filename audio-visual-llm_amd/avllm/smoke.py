@@ -13,7 +13,7 @@ def run():
     W = Wt.all_weights(oc, 0, lora_b_std=0.05)
     audio, video, labels, prompt = Wt.synthetic_batch(oc, 2, 5, seed=7)
     cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
-    m = ClipWhisperModel(device="cuda:0", use_fp16=False, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, max_seq_len=512,
+    m = ClipWhisperModel(device="cuda:0", use_fp16=False, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=512,
                          config=cfg, weights=W, precision="fp32")
     m.train()
     out = m(audio=audio.cuda(), video=video.cuda(), prompt=prompt.cuda(), labels=labels.cuda())

@@ -511,6 +511,89 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
     }
 }
 
+// Persistent form of the kernel above: one workgroup per CU walks tiles id, id+G, id+2G, ... and issues the FIRST K-tile of its
+// next output tile during the LAST K-step of the current one, so the per-tile prologue latency (exposed above, because a
+// 128 KiB workgroup has no co-resident partner) hides under compute and the epilogue stores overlap the next tile's loads.
+// Matters most for the short-K encoder GEMMs (K = 768: 12 K-steps per tile).
+__global__ __launch_bounds__(1024, 4) void gemm_bf16_hp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_m = (g.e.M + HBM_ - 1) / HBM_, tiles_n = (g.e.N + HBN_ - 1) / HBN_;
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto stage = [&](int m0, int n0, int t, int buf) {
+        char* a_lds = smem + buf * HSTAGE;
+        char* b_lds = a_lds + HBM_ * BK * 2;
+        const bf16* Ap = t < nt1 ? g.A : g.A2;
+        const bf16* Bp = t < nt1 ? g.B : g.B2;
+        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
+        const int k0 = (t < nt1 ? t : t - nt1) * BK;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows8(Ap, la, m0, g.e.M, k0, a_lds, p * 16 + wave, lane);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows8(Bp, lb, n0, g.e.N, k0, b_lds, p * 16 + wave, lane);
+    };
+
+    int tm, tn;
+    tile_coords(first, tiles_m, tiles_n, tm, tn);
+    int m0 = tm * HBM_, n0 = tn * HBN_;
+    int cur = 0;
+    stage(m0, n0, 0, 0);
+    __syncthreads();
+    for (int tile = first; tile < ntiles; tile += G) {
+        const int next = tile + G;
+        int nm0 = 0, nn0 = 0;
+        if (next < ntiles) { int a, b; tile_coords(next, tiles_m, tiles_n, a, b); nm0 = a * HBM_; nn0 = b * HBN_; }
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) stage(m0, n0, t + 1, cur ^ 1);
+            else if (next < ntiles) stage(nm0, nn0, 0, cur ^ 1);
+            const char* a_lds = smem + cur * HSTAGE;
+            const char* b_lds = a_lds + HBM_ * BK * 2;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xa[4], wb[4];
+                const int chunk = ks * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wm * 64 + i * 16 + fr;
+                    xa[i] = *(const bf16x8*)(a_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wn * 64 + j * 16 + fr;
+                    wb[j] = *(const bf16x8*)(b_lds + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < 4; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+            }
+        }
+        m0 = nm0; n0 = nn0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bf16, N == 64 (LoRA rank side)
 // C[M,64] = alpha * A[M,K] . B[64,K]^T.  A 128x128 tiling leaves 16 workgroups walking K serially (72 us measured at
 // M=2048, K=4096).  Here a workgroup owns 16 rows and splits K over its 8 waves (split-K inside the block, reduced
@@ -669,13 +752,17 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         const bool auto_h = variant == 0 && xtiles >= 200;          // 256x256 / 16 waves whenever it fills the chip (tools/gemm_bench.py)
         const bool auto_x = false;
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
-        if (d->M > 128 && (variant == 5 || auto_h)) {
+        if (d->M > 128 && (variant == 5 || variant == 6 || auto_h)) {
             static bool attr4 = false;
             if (!attr4) {
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE));
+                AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_hp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE));
                 attr4 = true;
             }
-            hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
+            static int ncu = 0;
+            if (!ncu) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
+            if (variant == 5) hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
+            else hipLaunchKernelGGL(gemm_bf16_hp_kernel, dim3(xtiles < ncu ? xtiles : ncu), dim3(1024), 2 * HSTAGE, st, g);
         } else if (d->M > 128 && (variant == 4 || auto_x)) {
             hipLaunchKernelGGL(gemm_bf16_x_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
         } else if (d->M > 128 && auto_l) {

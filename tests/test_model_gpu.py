@@ -20,7 +20,8 @@ def make_model(oc, W, precision, max_seq_len=512, dev="cuda:0"):
     from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
     from avllm.model import ClipWhisperModel
     cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
-    return ClipWhisperModel(device=dev, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, max_seq_len=max_seq_len, config=cfg, weights=W,
+    # parity runs use lora_dropout=0: it is the only stochastic op of the step; dropout has its own test below
+    return ClipWhisperModel(device=dev, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=max_seq_len, config=cfg, weights=W,
                             precision=precision)
 
 
