@@ -65,6 +65,7 @@ LAYER_CB = C.CFUNCTYPE(None, i32, vp)
 _SIGS = {
     "avllm_version": ([], i32),
     "avllm_gemm": ([C.POINTER(GemmDesc), vp], i32),
+    "avllm_set_gemm_variant": ([i32], i32),
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),
     "avllm_layernorm": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_fwd": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),

@@ -433,6 +433,92 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_x_kernel(GemmArgs g) {
     }
 }
 
+// Software-pipelined form of the 256x256 / 8-wave / 128x64-per-wave kernel: the 12 fragment reads of K-tile t+1 are issued
+// BEFORE the 32 MFMAs of K-tile t (two named register sets, loop unrolled by two), so the LDS latency and the LDS-DMA issue
+// sit under a 512-cycle MFMA block instead of in front of it.  tools/ubench/lds_mfma: this fragment shape sustains
+// 1.77 PF/s LDS-fed at 8 waves/CU (1.62 for 64x64 per wave).
+#define XP_LOAD_FRAGS(XA, WB, BUF)                                                                        \
+    {                                                                                                     \
+        const char* a_l = smem + (BUF) * XSTAGE + (wm * 128) * 64 + frag_off;                             \
+        const char* b_l = smem + (BUF) * XSTAGE + XBM * WBK * 2 + (wn * 64) * 64 + frag_off;              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) WB[j] = *(const bf16x8*)(b_l + j * 1024);           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) XA[i] = *(const bf16x8*)(a_l + i * 1024);           \
+    }
+#define XP_MFMA(XA, WB)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[j], XA[i], acc[i][j], 0, 0, 0);
+// one K-step: (tile T in registers CUR) -> make tile T+1 visible, refill the ring, prefetch T+1 fragments into NXT, compute T
+#define XP_STEP(T, CUR_XA, CUR_WB, NXT_XA, NXT_WB)                                                        \
+    {                                                                                                     \
+        if ((T) + 1 < nt) {                                                                               \
+            if ((T) + 2 < nt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+            else              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+        }                                                                                                 \
+        /* CUR's reads are complete here on every path: consume them so hipcc does not wait on the NEW reads below */ \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(CUR_XA[i]));                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(CUR_WB[j]));                 \
+        if ((T) + 1 < nt) {                                                                               \
+            if ((T) + 3 < nt) stage((T) + 3, ((T) + 3) & 3);                                              \
+            XP_LOAD_FRAGS(NXT_XA, NXT_WB, ((T) + 1) & 3)                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
+        XP_MFMA(CUR_XA, CUR_WB)                                                                           \
+    }
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_xp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_m = (g.e.M + XBM - 1) / XBM, tiles_n = (g.e.N + XBN - 1) / XBN;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * XBM, n0 = tn * XBN;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt1 = g.K / WBK, nt = nt1 + g.K2 / WBK;      // even: K and K2 are multiples of 64
+    auto stage = [&](int t, int buf) {
+        char* a_lds = smem + buf * XSTAGE;
+        char* b_lds = a_lds + XBM * WBK * 2;
+        const bf16* Ap = t < nt1 ? g.A : g.A2;
+        const bf16* Bp = t < nt1 ? g.B : g.B2;
+        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
+        const int k0 = (t < nt1 ? t : t - nt1) * WBK;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows16(Ap, la, m0, g.e.M, k0, a_lds, p * 8 + wave, lane);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) stage_rows16(Bp, lb, n0, g.e.N, k0, b_lds, p * 8 + wave, lane);
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag_off = fr * 64 + ((fq ^ swz64(fr)) << 4);
+
+    stage(0, 0);
+    stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    bf16x8 xaA[8], wbA[4], xaB[8], wbB[4];
+    XP_LOAD_FRAGS(xaA, wbA, 0)
+    for (int t = 0; t < nt; t += 2) {
+        XP_STEP(t, xaA, wbA, xaB, wbB)
+        XP_STEP(t + 1, xaB, wbB, xaA, wbA)
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + fr;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bf16, 256x256 tile, 16 waves x (64x64)
 // tools/ubench/gemm_ablate: at 128x128 the LDS-DMA stream alone (18.8 TB/s chip-wide, ~35 B/clk/CU) takes as long as the
 // ds_read+MFMA phase alone, so the tile is load-bound at ~56 % of MFMA peak.  This variant keeps the per-wave code of the
@@ -704,6 +790,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
 
 }  // namespace
 
+static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 3 256x128 reg-blocked, 4/7 256x256 8-wave, 5 256x256 16-wave, 6 persistent
+extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
 void av_prof_before(hipStream_t st);
 void av_prof_after(hipStream_t st, double flops);
@@ -736,7 +824,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LNSTAGE * LSTAGE));
             attr_set = true;
         }
-        static const int variant = getenv("AVLLM_GEMM_VARIANT") ? atoi(getenv("AVLLM_GEMM_VARIANT")) : 0;   // 1 = force 128x128
+        const int variant = g_gemm_variant >= 0 ? g_gemm_variant : (g_gemm_variant = getenv("AVLLM_GEMM_VARIANT") ? atoi(getenv("AVLLM_GEMM_VARIANT")) : 0);
         static bool attr2 = false;
         if (!attr2) {
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNSTAGE * WSTAGE));
@@ -763,6 +851,10 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
             if (!ncu) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
             if (variant == 5) hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
             else hipLaunchKernelGGL(gemm_bf16_hp_kernel, dim3(xtiles < ncu ? xtiles : ncu), dim3(1024), 2 * HSTAGE, st, g);
+        } else if (d->M > 128 && variant == 7) {
+            static bool attr5 = false;
+            if (!attr5) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_xp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XNSTAGE * XSTAGE)); attr5 = true; }
+            hipLaunchKernelGGL(gemm_bf16_xp_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
         } else if (d->M > 128 && (variant == 4 || auto_x)) {
             hipLaunchKernelGGL(gemm_bf16_x_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
         } else if (d->M > 128 && auto_l) {

@@ -54,6 +54,8 @@ typedef struct avllm_gemm_desc {
     float drop_p;                       /*   keep(drop_seed, m*N+n, p)/(1-p)  -- see avllm_dropout */
 } avllm_gemm_desc;
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
+/* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT) */
+int avllm_set_gemm_variant(int v);
 
 /* out[I,J] (f32, row stride ldo) += alpha * sum_m P[m,i]*Q[m,j]; LoRA dA/dB (autograd of peft lora.Linear) */
 int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,

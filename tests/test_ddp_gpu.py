@@ -1,0 +1,67 @@
+"""GPU: the real trainer step under torch.distributed with 2 ranks on one card (gloo carries the CUDA tensors, since RCCL
+refuses two ranks on one device): bucketed per-layer all-reduce driven by the C callback, token-count-weighted loss, replicated
+clip+AdamW.  Result must equal ONE process stepping on the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(dev):
+    sys.path.insert(0, os.path.join(ROOT, "audio-visual-llm_amd")); sys.path.insert(0, ROOT)
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    from avllm.trainer import ClipWhisperTrainer
+    from oracle import weights as Wt
+    oc = Wt.tiny()
+    W = Wt.all_weights(oc, 0, lora_b_std=0.05)
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    m = ClipWhisperModel(device=dev, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=512, config=cfg, weights=W,
+                         precision="fp32").train()
+    tr = ClipWhisperTrainer(m, learning_rate=1e-3, grad_clip=0.5, total_steps=10, max_epochs=1)
+    audio, video, labels, prompt = Wt.synthetic_batch(oc, 4, 3, seed=77)
+    labels[0, 12:] = oc.pad_token_id                      # uneven numbers of scored tokens across the two halves
+    return m, tr, audio, video, labels, prompt
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    m, tr, audio, video, labels, prompt = _build("cuda:0")
+    assert tr.reducer.enabled
+    sl = slice(rank * 2, rank * 2 + 2)
+    losses = []
+    for _ in range(2):
+        losses.append(float(tr.train_step(audio[sl].cuda(), video[sl].cuda(), labels[sl].cuda(), prompt[sl].cuda())))
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((losses, m.llm_engine.lora_p.cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    losses, params = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m, tr, audio, video, labels, prompt = _build("cuda:0")
+    ref_losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(2)]
+    ref = m.llm_engine.lora_p.cpu()
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-4, (losses, ref_losses)
+    init = _build("cuda:0")[0].llm_engine.lora_p.cpu()
+    rel = ((params - ref).norm() / (ref - init).norm()).item()
+    assert rel < 2e-2, rel                                   # relative to the size of the 2-step update

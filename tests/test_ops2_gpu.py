@@ -64,3 +64,21 @@ def test_attention_full_size(dev):
             err = (dqkv.float() - x.grad).pow(2).sum().sqrt() / x.grad.pow(2).sum().sqrt()
             assert err < 2e-2, err
             close(dqkv, x.grad, 8e-2, 5e-2, "attention bwd full size")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+def test_every_gemm_tiling_agrees(dev, variant):
+    """All bf16 tilings compiled into the library (A/B variants included) compute the same epilogue-fused GEMM."""
+    from avllm import lib as L
+    lib = L.load()
+    M, N, K, K2 = 700, 520, 256, 64
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=41), rnd(N, K, dtype=torch.bfloat16, seed=42)
+    A2, B2 = rnd(M, K2, dtype=torch.bfloat16, seed=43), rnd(N, K2, dtype=torch.bfloat16, seed=44)
+    bias, R = rnd(N, dtype=torch.bfloat16, seed=45), rnd(M, N, dtype=torch.bfloat16, seed=46)
+    ref = torch.nn.functional.gelu(A.float() @ B.float().t() + A2.float() @ B2.float().t() + bias.float()) + R.float()
+    try:
+        lib.avllm_set_gemm_variant(variant)
+        out = ops.gemm(A, B, bias=bias, R=R, A2=A2, B2=B2, act=L.ACT_GELU)
+    finally:
+        lib.avllm_set_gemm_variant(0)
+    close(out, ref, 0.3, 2e-2, f"gemm variant {variant}")

@@ -12,7 +12,7 @@ __device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) &
 // MODE 2: 64-B rows, F swizzle, 128x64 per wave, K-tile 32                         [gemm_bf16_x_kernel]
 // MODE 3: 64-B rows, no swizzle, 128x64
 template <int MODE>
-__global__ void k(const bf16* in, float* out, int iters) {
+__global__ __launch_bounds__(512, 2) void k(const bf16* in, float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) ((uint4*)smem)[i] = ((const uint4*)in)[i];
     __syncthreads();
