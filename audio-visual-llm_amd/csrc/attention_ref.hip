@@ -171,37 +171,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_ref(const T* __restrict__ q,
     if (lane + 64 < hd) { ok[lane + 64] = from_f<T>(gk1); ov[lane + 64] = from_f<T>(gv1); }
 }
 
-// single-token attention over a KV cache [B,Tmax,d]: block per (b,h), 256 threads
+// single-token attention over a KV cache [B,Tmax,d]: block per (b,h), 4 waves.  HBM/L2-bound row streaming: a group of
+// G = hd/8 lanes covers one K (or V) row with 16-byte loads, so one wave-instruction reads 64/G whole rows, coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, T* __restrict__ o, long ldo, int H, int hd, int Tk,
                                                           int Tmax, float scale) {
-    extern __shared__ float sh[];            // [hd] q  + [Tk] scores + 8 reduction + [4][hd] partial
-    float* qs = sh; float* sc = sh + hd; float* red = sc + Tk; float* part = red + 8;
+    extern __shared__ float sh[];            // [Tk] scores | 8 reduction | [4][hd] partial outputs
+    float* sc = sh; float* red = sc + Tk; float* part = red + 8;
     const int h = blockIdx.x, b = blockIdx.y, d = H * hd;
-    for (int c = threadIdx.x; c < hd; c += 256) qs[c] = to_f(q[(long)b * ldq + (long)h * hd + c]);
-    __syncthreads();
+    const int G = hd >> 3;                   // lanes per row (16 for hd=128, 8 for hd=64)
+    const int rows_per_pass = 256 / G;
+    const int tid = threadIdx.x, dc = tid % G, rsub = tid / G;
+    float qv[8];
+    load_f<8>(q + (long)b * ldq + (long)h * hd + dc * 8, qv);
+    const T* kbase = kc + ((long)b * Tmax) * d + (long)h * hd + dc * 8;
+    const T* vbase = vc + ((long)b * Tmax) * d + (long)h * hd + dc * 8;
     float mx = -INFINITY;
-    for (int j = threadIdx.x; j < Tk; j += 256) {
-        const float s = scale * dot_row(qs, kc + ((long)b * Tmax + j) * d + (long)h * hd, hd);
-        sc[j] = s; mx = fmaxf(mx, s);
+    for (int t0 = 0; t0 < Tk; t0 += rows_per_pass) {
+        const int t = t0 + rsub;
+        float s = 0.f;
+        if (t < Tk) {
+            float kv[8];
+            load_f<8>(kbase + (long)t * d, kv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += qv[j] * kv[j];
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);      // reduce inside the G-lane group
+        s *= scale;
+        if (t < Tk) { if (dc == 0) sc[t] = s; mx = fmaxf(mx, s); }
     }
     mx = block_max(mx, red);
     float sm = 0.f;
-    for (int j = threadIdx.x; j < Tk; j += 256) { const float p = __expf(sc[j] - mx); sc[j] = p; sm += p; }
-    sm = block_sum(sm, red);
-    // 256 threads = up to 4 key-groups x 64.. hd columns
-    const int groups = 256 / hd > 0 ? 256 / hd : 1;
-    const int gi = threadIdx.x / hd, c = threadIdx.x % hd;
-    float acc = 0.f;
-    if (gi < groups)
-        for (int j = gi; j < Tk; j += groups) acc += sc[j] * to_f(vc[((long)b * Tmax + j) * d + (long)h * hd + c]);
-    if (gi < groups) part[gi * hd + c] = acc;
+    for (int j = tid; j < Tk; j += 256) { const float p = __expf(sc[j] - mx); sc[j] = p; sm += p; }
+    sm = block_sum(sm, red);                 // (contains the barriers that publish sc[])
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < Tk; t0 += rows_per_pass) {
+        const int t = t0 + rsub;
+        if (t < Tk) {
+            float vv[8];
+            load_f<8>(vbase + (long)t * d, vv);
+            const float p = sc[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += p * vv[j];
+        }
+    }
+    // reduce over the row groups of a wave (lanes with equal dc), then over the 4 waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int off = G; off < 64; off <<= 1) acc[j] += __shfl_xor(acc[j], off);
+    const int w = tid >> 6, lane = tid & 63;
+    if (lane < G) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[w * hd + lane * 8 + j] = acc[j];
+    }
     __syncthreads();
-    if (threadIdx.x < hd) {
-        float t = 0.f;
-        for (int g = 0; g < groups; ++g) t += part[g * hd + threadIdx.x];
-        o[(long)b * ldo + (long)h * hd + threadIdx.x] = from_f<T>(t / sm);
+    if (tid < hd) {
+        const float t = part[tid] + part[hd + tid] + part[2 * hd + tid] + part[3 * hd + tid];
+        o[(long)b * ldo + (long)h * hd + tid] = from_f<T>(t / sm);
     }
 }
 
@@ -244,8 +271,8 @@ int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void
 int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st) {
     AV_CHECK_ARG(q && kc && vc && o && Tk > 0 && Tk <= Tmax, "attention_decode: bad args");
-    AV_CHECK_ARG(hd % 8 == 0 && hd <= 256 && 256 % hd == 0, "attention_decode: head_dim %d unsupported", hd);
-    const size_t sh = (size_t)(hd + Tk + 8 + 4 * hd) * sizeof(float);
+    AV_CHECK_ARG((hd == 64 || hd == 128) && ldq % 8 == 0, "attention_decode: head_dim %d unsupported", hd);
+    const size_t sh = (size_t)(Tk + 8 + 4 * hd) * sizeof(float);
     AV_CHECK_ARG(sh <= 64 * 1024, "attention_decode: Tk=%d too long for the LDS score buffer", Tk);
     const dim3 grid(H, B);
     if (dtype == AV_F32) hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), sh, st, (const float*)q, ldq, (const float*)kc, (const float*)vc, (float*)o, ldo, H, hd, Tk, Tmax, scale);

@@ -436,6 +436,10 @@ int llama_infer_layer(const avllm_llama* m, int l, LlamaInferWs& w, int B, int S
     char* kcl = (char*)kc + (size_t)l * B * Tmax * d * es;
     char* vcl = (char*)vc + (size_t)l * B * Tmax * d * es;
     AV_TRY(av_rmsnorm_fwd(w.x, P.ln1_w, w.xn, nullptr, M, d, m->eps, dt, st));
+    if (!P.lora[0].A_pad && !P.lora[1].A_pad && !P.lora[2].A_pad) {      // no adapters (decode.py path): one fused q|k|v projection
+        avllm_gemm_desc gq = gemm_desc(dt, w.xn, d, P.wqkv, d, w.qkv, 3 * d, M, 3 * d, d);
+        AV_TRY(av_gemm(&gq, st));
+    } else
     for (int j = 0; j < 3; ++j)
         AV_TRY(lora_proj(m, w.xn, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j], w.t, AVLLM_LORA_PAD,
                          (char*)w.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));

@@ -268,257 +268,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_l_kernel(GemmArgs g) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ bf16, 256x128 tile, 4 waves x (128x64)
-// Register-blocked variant.  The 64x64-per-wave kernels above issue one ds_read_b128 per two MFMAs and measure LDS-bound
-// (~0.9 LDS-busy per MFMA cycle at 8 waves/CU).  Here each wave owns 128x64 (8x4 accumulators, 128 AGPRs): 12 fragment reads
-// feed 32 MFMAs.  BK = 32 (64-byte LDS rows, 24 KiB per stage) with a 3-deep ring = 72 KiB, so two workgroups fit per CU and
-// overlap each other's barriers; counted vmcnt(6) keeps two K-tiles of global_load_lds in flight.
-// 64-byte rows need their own swizzle: physical chunk = logical chunk ^ F[(row>>2)&3], F = {0,2,3,1}; with the four
-// ds_read_b128 lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},{32-35,44-47,52-59},{36-43,48-51,60-63} every group then
-// touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
-constexpr int WBM = 256, WBN = 128, WBK = 32;
-constexpr int WSTAGE = (WBM + WBN) * WBK * 2;      // 24 KiB
-constexpr int WNSTAGE = 3;
-
-__device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // F = {0,2,3,1}
-
-__device__ __forceinline__ void stage_rows16(const bf16* __restrict__ base, long ld, int row0, int rows_max, int k0, char* lds,
-                                             int group, int lane) {
-    // one wave-instruction: 16 rows x 64 B at LDS rows [group*16, group*16+16)
-    const int rsub = lane >> 2;
-    int gr = row0 + group * 16 + rsub;
-    gr = gr < rows_max ? gr : rows_max - 1;
-    const bf16* src = base + (long)gr * ld + k0 + (((lane & 3) ^ swz64(rsub)) << 3);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + group * 1024), 16, 0, 0);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_bf16_w_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_m = (g.e.M + WBM - 1) / WBM, tiles_n = (g.e.N + WBN - 1) / WBN;
-    int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * WBM, n0 = tn * WBN;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nt1 = g.K / WBK, nt = nt1 + g.K2 / WBK;
-    auto stage = [&](int t, int buf) {
-        char* a_lds = smem + buf * WSTAGE;
-        char* b_lds = a_lds + WBM * WBK * 2;
-        const bf16* Ap = t < nt1 ? g.A : g.A2;
-        const bf16* Bp = t < nt1 ? g.B : g.B2;
-        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
-        const int k0 = (t < nt1 ? t : t - nt1) * WBK;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) stage_rows16(Ap, la, m0, g.e.M, k0, a_lds, p * 4 + wave, lane);     // 16 groups = 256 rows
-#pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows16(Bp, lb, n0, g.e.N, k0, b_lds, p * 4 + wave, lane);     // 8 groups = 128 rows
-    };
-
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    const int fr = lane & 15, fq = lane >> 4;
-    // per-lane LDS byte offsets of the fragment rows (row = 16*tile + fr  ->  (row>>2)&3 == (fr>>2))
-    const int frag_off = fr * 64 + ((fq ^ swz64(fr)) << 4);
-    int buf = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + 2 < nt) stage(t + 2, buf >= 1 ? buf - 1 : WNSTAGE - 1);
-        const char* a_lds = smem + buf * WSTAGE + (wm * 128) * 64 + frag_off;
-        const char* b_lds = smem + buf * WSTAGE + WBM * WBK * 2 + (wn * 64) * 64 + frag_off;
-        bf16x8 wb[4], xa[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(b_lds + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xa[i] = *(const bf16x8*)(a_lds + i * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-        buf = buf + 1 == WNSTAGE ? 0 : buf + 1;
-    }
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + fr;
-#pragma clang loop unroll(full)
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ bf16, 256x256 tile, 8 waves x (128x64)
-// Measured on MI355X (tools/gemm_bench.py): the 128x128 and 256x128 kernels all sit at 0.8-1.0 PFLOP/s whatever their
-// barrier/prefetch structure; what they share is the global->LDS byte rate they need per MFMA cycle (64 resp. 48 B/clk/CU
-// at full MFMA rate against a practical LDS-DMA rate of 30-40 B/clk/CU).  A 256x256 tile needs 32 B/clk/CU.  8 waves (2x4),
-// 128x64 per wave, BK=32, 4-deep ring (4 x 32 KiB = 128 KiB, one workgroup per CU), three K-tiles of LDS-DMA in flight behind
-// a counted vmcnt, one raw barrier per K-tile.
-constexpr int XBM = 256, XBN = 256;
-constexpr int XSTAGE = (XBM + XBN) * WBK * 2;      // 32 KiB
-constexpr int XNSTAGE = 4;
-
-__global__ __launch_bounds__(512, 2) void gemm_bf16_x_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tiles_m = (g.e.M + XBM - 1) / XBM, tiles_n = (g.e.N + XBN - 1) / XBN;
-    int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * XBM, n0 = tn * XBN;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nt1 = g.K / WBK, nt = nt1 + g.K2 / WBK;
-    auto stage = [&](int t, int buf) {
-        char* a_lds = smem + buf * XSTAGE;
-        char* b_lds = a_lds + XBM * WBK * 2;
-        const bf16* Ap = t < nt1 ? g.A : g.A2;
-        const bf16* Bp = t < nt1 ? g.B : g.B2;
-        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
-        const int k0 = (t < nt1 ? t : t - nt1) * WBK;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows16(Ap, la, m0, g.e.M, k0, a_lds, p * 8 + wave, lane);     // 16 groups = 256 rows
-#pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows16(Bp, lb, n0, g.e.N, k0, b_lds, p * 8 + wave, lane);
-    };
-
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    if (nt > 2) stage(2, 2);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int frag_off = fr * 64 + ((fq ^ swz64(fr)) << 4);
-    int buf = 0;
-    for (int t = 0; t < nt; ++t) {
-        const int ahead = nt - 1 - t;                      // K-tiles already issued beyond t (capped at 2)
-        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + 3 < nt) stage(t + 3, buf >= 1 ? buf - 1 : XNSTAGE - 1);        // (t+3) % 4 == (buf+3) % 4
-        const char* a_lds = smem + buf * XSTAGE + (wm * 128) * 64 + frag_off;
-        const char* b_lds = smem + buf * XSTAGE + XBM * WBK * 2 + (wn * 64) * 64 + frag_off;
-        bf16x8 wb[4], xa[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(b_lds + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xa[i] = *(const bf16x8*)(a_lds + i * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-        buf = buf + 1 == XNSTAGE ? 0 : buf + 1;
-    }
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + fr;
-#pragma clang loop unroll(full)
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
-        }
-    }
-}
-
-// Software-pipelined form of the 256x256 / 8-wave / 128x64-per-wave kernel: the 12 fragment reads of K-tile t+1 are issued
-// BEFORE the 32 MFMAs of K-tile t (two named register sets, loop unrolled by two), so the LDS latency and the LDS-DMA issue
-// sit under a 512-cycle MFMA block instead of in front of it.  tools/ubench/lds_mfma: this fragment shape sustains
-// 1.77 PF/s LDS-fed at 8 waves/CU (1.62 for 64x64 per wave).
-#define XP_LOAD_FRAGS(XA, WB, BUF)                                                                        \
-    {                                                                                                     \
-        const char* a_l = smem + (BUF) * XSTAGE + (wm * 128) * 64 + frag_off;                             \
-        const char* b_l = smem + (BUF) * XSTAGE + XBM * WBK * 2 + (wn * 64) * 64 + frag_off;              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) WB[j] = *(const bf16x8*)(b_l + j * 1024);           \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) XA[i] = *(const bf16x8*)(a_l + i * 1024);           \
-    }
-#define XP_MFMA(XA, WB)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                         \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[j], XA[i], acc[i][j], 0, 0, 0);
-// one K-step: (tile T in registers CUR) -> make tile T+1 visible, refill the ring, prefetch T+1 fragments into NXT, compute T
-#define XP_STEP(T, CUR_XA, CUR_WB, NXT_XA, NXT_WB)                                                        \
-    {                                                                                                     \
-        if ((T) + 1 < nt) {                                                                               \
-            if ((T) + 2 < nt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
-            else              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
-        }                                                                                                 \
-        /* CUR's reads are complete here on every path: consume them so hipcc does not wait on the NEW reads below */ \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(CUR_XA[i]));                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(CUR_WB[j]));                 \
-        if ((T) + 1 < nt) {                                                                               \
-            if ((T) + 3 < nt) stage((T) + 3, ((T) + 3) & 3);                                              \
-            XP_LOAD_FRAGS(NXT_XA, NXT_WB, ((T) + 1) & 3)                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
-        }                                                                                                 \
-        XP_MFMA(CUR_XA, CUR_WB)                                                                           \
-    }
-
-__global__ __launch_bounds__(512, 2) void gemm_bf16_xp_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tiles_m = (g.e.M + XBM - 1) / XBM, tiles_n = (g.e.N + XBN - 1) / XBN;
-    int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * XBM, n0 = tn * XBN;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nt1 = g.K / WBK, nt = nt1 + g.K2 / WBK;      // even: K and K2 are multiples of 64
-    auto stage = [&](int t, int buf) {
-        char* a_lds = smem + buf * XSTAGE;
-        char* b_lds = a_lds + XBM * WBK * 2;
-        const bf16* Ap = t < nt1 ? g.A : g.A2;
-        const bf16* Bp = t < nt1 ? g.B : g.B2;
-        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
-        const int k0 = (t < nt1 ? t : t - nt1) * WBK;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows16(Ap, la, m0, g.e.M, k0, a_lds, p * 8 + wave, lane);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows16(Bp, lb, n0, g.e.N, k0, b_lds, p * 8 + wave, lane);
-    };
-    const int fr = lane & 15, fq = lane >> 4;
-    const int frag_off = fr * 64 + ((fq ^ swz64(fr)) << 4);
-
-    stage(0, 0);
-    stage(1, 1);
-    if (nt > 2) stage(2, 2);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    bf16x8 xaA[8], wbA[4], xaB[8], wbB[4];
-    XP_LOAD_FRAGS(xaA, wbA, 0)
-    for (int t = 0; t < nt; t += 2) {
-        XP_STEP(t, xaA, wbA, xaB, wbB)
-        XP_STEP(t + 1, xaB, wbB, xaA, wbA)
-    }
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + fr;
-#pragma clang loop unroll(full)
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue_store4<bf16>(g.e, m, n0 + wn * 64 + j * 16 + fq * 4, v);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ bf16, 256x256 tile, 16 waves x (64x64)
 // tools/ubench/gemm_ablate: at 128x128 the LDS-DMA stream alone (18.8 TB/s chip-wide, ~35 B/clk/CU) takes as long as the
 // ds_read+MFMA phase alone, so the tile is load-bound at ~56 % of MFMA peak.  This variant keeps the per-wave code of the
@@ -597,7 +346,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
     }
 }
 
-// Persistent form of the kernel above: one workgroup per CU walks tiles id, id+G, id+2G, ... and issues the FIRST K-tile of its
+// Persistent form of the 16-wave kernel (gemm_bf16_h_kernel): one workgroup per CU walks tiles id, id+G, id+2G, ... and issues the FIRST K-tile of its
 // next output tile during the LAST K-step of the current one, so the per-tile prologue latency (exposed above, because a
 // 128 KiB workgroup has no co-resident partner) hides under compute and the epilogue stores overlap the next tile's loads.
 // Matters most for the short-K encoder GEMMs (K = 768: 12 K-steps per tile).
@@ -725,6 +474,52 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16, M <= 16 (greedy decode steps)
+// HBM-bound weight streaming: every decode step reads all 13.5 GB of bf16 Llama-2-7B weights once, whatever the batch
+// (SURVEY.md §8d).  A workgroup owns 16 output columns (16 rows of W, streamed once, straight from global into MFMA
+// fragments -- no LDS round trip for data without reuse), splits K over its 8 waves with 8 x 2 KiB of loads in flight per wave,
+// and reduces the 8 partial 16x16 tiles through LDS.  The (<=16) activation rows ride along as the other MFMA operand.
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_smallm_kernel(GemmArgs g) {
+    __shared__ float part[SK_WAVES][16][17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int M = g.e.M;
+    const int ar = fr < M ? fr : M - 1;
+    const int kw = g.K / SK_WAVES;
+    const bf16* ap = g.A + (long)ar * g.lda + (long)w * kw + fq * 8;
+    const bf16* bp = g.B + (long)(n0 + fr) * g.ldb + (long)w * kw + fq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k < kw; k += 32) {
+        const bf16x8 wb = *(const bf16x8*)(bp + k);
+        const bf16x8 xa = *(const bf16x8*)(ap + k);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc, 0, 0, 0);          // D[n][m]
+    }
+    if (w == 0 && g.K2 > 0) {
+        const bf16* ap2 = g.A2 + (long)ar * g.lda2 + fq * 8;
+        const bf16* bp2 = g.B2 + (long)(n0 + fr) * g.ldb2 + fq * 8;
+        for (int k = 0; k < g.K2; k += 32)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(bp2 + k), *(const bf16x8*)(ap2 + k), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[w][fq * 4 + i][fr] = acc[i];                      // [n][m]
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int m = threadIdx.x >> 4, nn = threadIdx.x & 15, n = n0 + nn;
+        if (m < M && n < g.e.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int x = 0; x < SK_WAVES; ++x) s += part[x][nn][m];
+            s = s * g.e.alpha + (g.e.bias ? to_f(((const bf16*)g.e.bias)[n]) : 0.f);
+            s = act_apply(s, g.e.act);
+            if (g.e.R) s += to_f(((const bf16*)g.e.R)[(long)(g.e.r_mod > 0 ? m % g.e.r_mod : m) * g.e.ldr + n]);
+            if (g.e.out_f32) ((float*)g.e.C)[(long)m * g.e.ldc + n] = s;
+            else ((bf16*)g.e.C)[(long)m * g.e.ldc + n] = (bf16)s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ f32
 constexpr int FM = 64, FN = 64, FK = 16, FLD = FK + 1;
 
@@ -790,7 +585,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
 
 }  // namespace
 
-static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 3 256x128 reg-blocked, 4/7 256x256 8-wave, 5 256x256 16-wave, 6 persistent
+static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent
 extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
 void av_prof_before(hipStream_t st);
@@ -810,7 +605,13 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     e.drop_seed = d->drop_seed; e.drop_p = d->drop_p;
     const bool prof = av_prof_enabled();
     if (prof) av_prof_before(st);
-    if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
+    if (d->dtype == AV_BF16 && d->M <= 16 && d->N % 16 == 0 && d->K % (32 * SK_WAVES) == 0 && d->K2 % 32 == 0 && d->g_in == 0 &&
+        d->drop_p <= 0.f && g_gemm_variant <= 0) {
+        GemmArgs g;
+        g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
+        g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
+        hipLaunchKernelGGL(gemm_smallm_kernel, dim3(d->N / 16), dim3(SK_WAVES * 64), 0, st, g);
+    } else if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
         d->K % (32 * SK_WAVES) == 0 && d->M >= 256) {
         hipLaunchKernelGGL(gemm_skinny64_kernel, dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
                            (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32);
@@ -825,20 +626,11 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
             attr_set = true;
         }
         const int variant = g_gemm_variant >= 0 ? g_gemm_variant : (g_gemm_variant = getenv("AVLLM_GEMM_VARIANT") ? atoi(getenv("AVLLM_GEMM_VARIANT")) : 0);
-        static bool attr2 = false;
-        if (!attr2) {
-            AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNSTAGE * WSTAGE));
-            attr2 = true;
-        }
-        static bool attr3 = false;
-        if (!attr3) {
-            AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XNSTAGE * XSTAGE));
-            attr3 = true;
-        }
+        constexpr int XBM = 256, XBN = 256;
         const int xtiles = av_cdiv(d->M, XBM) * av_cdiv(d->N, XBN);
-        // auto choice from tools/gemm_bench.py on MI355X: 256x256 for very wide N, 256x128/8 waves for very long K, else 128x128
-        const bool auto_h = variant == 0 && xtiles >= 200;          // 256x256 / 16 waves whenever it fills the chip (tools/gemm_bench.py)
-        const bool auto_x = false;
+        // automatic choice (tools/gemm_bench.py on MI355X): 256x256 / 16 waves whenever it fills the chip, 256x128 ring for very
+        // long K with few tiles, else 128x128 with two workgroups per CU
+        const bool auto_h = variant == 0 && xtiles >= 200;
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
         if (d->M > 128 && (variant == 5 || variant == 6 || auto_h)) {
             static bool attr4 = false;
@@ -851,19 +643,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
             if (!ncu) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
             if (variant == 5) hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
             else hipLaunchKernelGGL(gemm_bf16_hp_kernel, dim3(xtiles < ncu ? xtiles : ncu), dim3(1024), 2 * HSTAGE, st, g);
-        } else if (d->M > 128 && variant == 7) {
-            static bool attr5 = false;
-            if (!attr5) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_xp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XNSTAGE * XSTAGE)); attr5 = true; }
-            hipLaunchKernelGGL(gemm_bf16_xp_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
-        } else if (d->M > 128 && (variant == 4 || auto_x)) {
-            hipLaunchKernelGGL(gemm_bf16_x_kernel, dim3(xtiles), dim3(512), XNSTAGE * XSTAGE, st, g);
-        } else if (d->M > 128 && auto_l) {
-            const int tiles = av_cdiv(d->M, LBM) * av_cdiv(d->N, LBN);
-            hipLaunchKernelGGL(gemm_bf16_l_kernel, dim3(tiles), dim3(512), LNSTAGE * LSTAGE, st, g);
-        } else if (d->M > 128 && variant == 3) {
-            const int tiles = av_cdiv(d->M, WBM) * av_cdiv(d->N, WBN);
-            hipLaunchKernelGGL(gemm_bf16_w_kernel, dim3(tiles), dim3(256), WNSTAGE * WSTAGE, st, g);
-        } else if (d->M > 128 && variant == 2) {
+        } else if (d->M > 128 && (variant == 2 || auto_l)) {
             const int tiles = av_cdiv(d->M, LBM) * av_cdiv(d->N, LBN);
             hipLaunchKernelGGL(gemm_bf16_l_kernel, dim3(tiles), dim3(512), LNSTAGE * LSTAGE, st, g);
         } else {
