@@ -66,6 +66,40 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& e, int m, int n
     }
 }
 
+// v[8] = 8 consecutive output columns of logical row m; every pointer is 16-byte aligned on this path (checked at launch).
+// Single rounding: bias/activation/dropout/residual are applied to the fp32 accumulator, then one convert + one 16-byte store.
+__device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n0, float (&v)[8]) {
+    if (e.bias) {
+        float b[8];
+        load_f<8>((const bf16*)e.bias + n0, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * e.alpha + b[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+    }
+    if (e.act != AV_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], e.act);
+    }
+    if (e.drop_p > 0.f) {
+        const float sc = 1.0f / (1.0f - e.drop_p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = av_keep(e.drop_seed, (unsigned long long)m * e.N + n0 + i, e.drop_p) ? v[i] * sc : 0.f;
+    }
+    if (e.R) {
+        const long rr = e.r_mod > 0 ? (m % e.r_mod) : m;
+        float r[8];
+        load_f<8>((const bf16*)e.R + rr * e.ldr + n0, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += r[i];
+    }
+    long orow = m;
+    if (e.g_in > 0) orow = (long)(m / e.g_in) * e.g_out + e.g_off + (m % e.g_in);
+    if (e.out_f32) store_f<8>((float*)e.C + orow * e.ldc + n0, v);
+    else store_f<8>((bf16*)e.C + orow * e.ldc + n0, v);
+}
+
 // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
 // range of logical tile ids.  Bijective for any grid size (cdna guide §5, "XCD swizzle must be bijective").
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -87,6 +121,7 @@ struct GemmArgs {
     const bf16* A; const bf16* B; const bf16* A2; const bf16* B2;
     long lda, ldb, lda2, ldb2;
     int K, K2;
+    int wide_epi;        // outputs/bias/residual 16-byte aligned, N % 8 == 0: LDS-staged epilogue with 16-byte row-coalesced stores
     EpiParams e;
 };
 
@@ -334,6 +369,40 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (g.wide_epi) {
+        // Epilogue through LDS (both stages are free after the last barrier).  Per-lane 8-byte stores of the MFMA layout are
+        // store-ISSUE-bound (~7 B/clk/CU: 128 KiB of output cost ~9 us per tile, 30 % of a K=768 tile); here each half tile goes
+        // to LDS as fp32 and comes back as whole 16-byte row chunks: bias/residual loads and the stores are row-coalesced.
+        constexpr int CT_LD = 256;                           // floats per LDS row; 16-byte chunk index XOR (row & 7) instead of padding
+        float* ct = (float*)smem;                            // [128][256] fp32 = 131,072 B = 2 * HSTAGE exactly
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((wm >> 1) == half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        const int row = (wm & 1) * 64 + i * 16 + fr;
+                        *(f32x4*)(ct + row * CT_LD + (((wn * 16 + j * 4 + fq) ^ (row & 7)) << 2)) = acc[i][j];
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int idx = p * 1024 + tid, row = idx >> 5, ch = idx & 31;
+                const int m = m0 + half * 128 + row, n = n0 + ch * 8;
+                if (m < g.e.M && n < g.e.N) {
+                    const f32x4 lo = *(const f32x4*)(ct + row * CT_LD + (((2 * ch) ^ (row & 7)) << 2));
+                    const f32x4 hi = *(const f32x4*)(ct + row * CT_LD + (((2 * ch + 1) ^ (row & 7)) << 2));
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    epilogue_store8(g.e, m, n, v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
     }
 #pragma clang loop unroll(full)
     for (int i = 0; i < 4; ++i) {
@@ -605,11 +674,16 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     e.drop_seed = d->drop_seed; e.drop_p = d->drop_p;
     const bool prof = av_prof_enabled();
     if (prof) av_prof_before(st);
+    const size_t osz = e.out_f32 ? 4 : 2;
+    const bool wide_ok = d->dtype == AV_BF16 && d->N % 8 == 0 && ((uintptr_t)d->C % 16 == 0) && (d->ldc * osz) % 16 == 0 &&
+                         (!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->R || ((uintptr_t)d->R % 16 == 0 && d->ldr % 8 == 0)) &&
+                         !getenv("AVLLM_NARROW_EPILOGUE");
     if (d->dtype == AV_BF16 && d->M <= 16 && d->N % 16 == 0 && d->K % (32 * SK_WAVES) == 0 && d->K2 % 32 == 0 && d->g_in == 0 &&
         d->drop_p <= 0.f && g_gemm_variant <= 0) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
+        g.wide_epi = wide_ok;
         hipLaunchKernelGGL(gemm_smallm_kernel, dim3(d->N / 16), dim3(SK_WAVES * 64), 0, st, g);
     } else if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
         d->K % (32 * SK_WAVES) == 0 && d->M >= 256) {
@@ -619,6 +693,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
+        g.wide_epi = wide_ok;
         static bool attr_set = false;
         if (!attr_set) {
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
@@ -641,7 +716,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
             }
             static int ncu = 0;
             if (!ncu) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
-            if (variant == 5) hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
+            if (variant != 6) hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
             else hipLaunchKernelGGL(gemm_bf16_hp_kernel, dim3(xtiles < ncu ? xtiles : ncu), dim3(1024), 2 * HSTAGE, st, g);
         } else if (d->M > 128 && (variant == 2 || auto_l)) {
             const int tiles = av_cdiv(d->M, LBM) * av_cdiv(d->N, LBN);
