@@ -68,20 +68,40 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
     const bool wave_active = q0 < Tq;
     const int wave_kmax = CAUSAL ? min(Tk - 1, min(Tq - 1, q0 + 31) + off) : Tk - 1;
 
-    for (int kb = 0; kb < k_end; kb += 64) {
-        __syncthreads();                       // previous tile fully consumed
-        for (int c = tid; c < 64 * CPR; c += NT) {
+    // K/V tiles are staged global -> registers -> LDS; the loads of tile t+1 are issued right after tile t has been
+    // written to LDS, so their latency runs under tile t's MFMA/softmax work (async-STAGE split, cdna guide T14).
+    constexpr int NCH = (64 * CPR + NT - 1) / NT;
+    // only where the extra 8*NCH VGPRs do not cost a resident workgroup: long non-causal sequences (Whisper, T=1500)
+    constexpr bool PREFETCH = (HD == 64 && NW == 4);
+    u32x4 kreg[NCH], vreg[NCH];
+    auto prefetch = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NT;
             const int row = c / CPR, ch = c % CPR;
-            const int key = kb + row;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (key < Tk) {
-                kv = *(const u32x4*)(k + ((long)b * Tk + key) * ldk + (long)hh * HD + ch * 8);
-                vv = *(const u32x4*)(v + ((long)b * Tk + key) * ldv + (long)hh * HD + ch * 8);
+            const int key = kb0 + row;
+            kreg[i] = (u32x4){0u, 0u, 0u, 0u}; vreg[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (c < 64 * CPR && key < Tk) {
+                kreg[i] = *(const u32x4*)(k + ((long)b * Tk + key) * ldk + (long)hh * HD + ch * 8);
+                vreg[i] = *(const u32x4*)(v + ((long)b * Tk + key) * ldv + (long)hh * HD + ch * 8);
             }
-            *(u32x4*)(k_lds + row * KS + ch * 16) = kv;
-            *(u32x4*)(v_lds + row * VS + ch * 16) = vv;
+        }
+    };
+    if (PREFETCH) prefetch(0);
+    for (int kb = 0; kb < k_end; kb += 64) {
+        if (!PREFETCH) prefetch(kb);
+        __syncthreads();                       // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NT;
+            if (c < 64 * CPR) {
+                const int row = c / CPR, ch = c % CPR;
+                *(u32x4*)(k_lds + row * KS + ch * 16) = kreg[i];
+                *(u32x4*)(v_lds + row * VS + ch * 16) = vreg[i];
+            }
         }
         __syncthreads();
+        if (PREFETCH && kb + 64 < k_end) prefetch(kb + 64);
         if (!wave_active || kb > wave_kmax) continue;      // wave-uniform
 
         const bool two = (kb + 32 <= wave_kmax) && (kb + 32 < Tk);   // second 32-key sub-block has visible keys
@@ -100,25 +120,29 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
             }
         }
-        // mask + block max
+        // mask (edge / diagonal blocks only) + block max on the RAW scores; the scale rides in the exp2's fma
         const int klim = CAUSAL ? min(Tk - 1, qpos + off) : Tk - 1;
+        const bool need_mask = (kb + 64 > Tk) || !two || (CAUSAL && kb + 63 > q0 + off);
         float mloc = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key0 = kb + acc_row(i, half);
-            s0[i] = key0 <= klim ? s0[i] * scale_log2e : -INFINITY;
-            s1[i] = (two && key0 + 32 <= klim) ? s1[i] * scale_log2e : -INFINITY;
-            mloc = fmaxf(mloc, fmaxf(s0[i], s1[i]));
+            for (int i = 0; i < 16; ++i) {
+                const int key0 = kb + acc_row(i, half);
+                s0[i] = key0 <= klim ? s0[i] : -INFINITY;
+                s1[i] = (two && key0 + 32 <= klim) ? s1[i] : -INFINITY;
+            }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, fmaxf(s0[i], s1[i]));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32)) * scale_log2e;
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = exp2f(m_run - m_use);
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            s0[i] = exp2f(s0[i] - m_use);
-            s1[i] = exp2f(s1[i] - m_use);
+            s0[i] = exp2f(fmaf(s0[i], scale_log2e, -m_use));
+            s1[i] = exp2f(fmaf(s1[i], scale_log2e, -m_use));
             psum += s0[i] + s1[i];
         }
         l_run = l_run * alpha + psum;

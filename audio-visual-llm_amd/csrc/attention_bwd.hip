@@ -32,16 +32,30 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int stride, int row0,
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <int HD, int NT>
-__device__ __forceinline__ void stage_rows(const bf16* __restrict__ src, long ld, int row0, int nrows, int rows_max, char* img_a,
-                                           int stride_a, char* img_b, int stride_b, int tid) {
-    constexpr int CPR = HD / 8;
-    for (int c = tid; c < nrows * CPR; c += NT) {
-        const int row = c / CPR, ch = c % CPR;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + row < rows_max) v = *(const u32x4*)(src + (long)(row0 + row) * ld + ch * 8);
-        if (img_a) *(u32x4*)(img_a + row * stride_a + ch * 16) = v;
-        if (img_b) *(u32x4*)(img_b + row * stride_b + ch * 16) = v;
+// Tiles go global -> registers -> LDS: the loads of the NEXT tile are issued right after the current tile has been written to
+// LDS, so their latency runs under the current tile's MFMA work (these kernels hold one workgroup per CU: nothing else hides it).
+template <int HD, int NT, int ROWS> struct RowRegs { u32x4 v[(ROWS * (HD / 8) + NT - 1) / NT]; };
+
+template <int HD, int NT, int ROWS>
+__device__ __forceinline__ void load_rows(RowRegs<HD, NT, ROWS>& r, const bf16* __restrict__ src, long ld, int row0, int rows_max, int tid) {
+    constexpr int CPR = HD / 8, N = (ROWS * CPR + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
+        r.v[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (c < ROWS * CPR && row0 + row < rows_max) r.v[i] = *(const u32x4*)(src + (long)(row0 + row) * ld + ch * 8);
+    }
+}
+template <int HD, int NT, int ROWS>
+__device__ __forceinline__ void store_rows(const RowRegs<HD, NT, ROWS>& r, char* img_a, int stride_a, char* img_b, int stride_b, int tid) {
+    constexpr int CPR = HD / 8, N = (ROWS * CPR + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
+        if (c < ROWS * CPR) {
+            if (img_a) *(u32x4*)(img_a + row * stride_a + ch * 16) = r.v[i];
+            if (img_b) *(u32x4*)(img_b + row * stride_b + ch * 16) = r.v[i];
+        }
     }
 }
 
@@ -86,11 +100,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_mfma(const bf16* __restri
     const bf16* kbase = k + (long)b * T * ldk + (long)hh * HD;
     const bf16* vbase = v + (long)b * T * ldv + (long)hh * HD;
 
+    RowRegs<HD, NT, 64> kr, vr;
+    load_rows<HD, NT, 64>(kr, kbase, ldk, 0, T, tid);
+    load_rows<HD, NT, 64>(vr, vbase, ldv, 0, T, tid);
     for (int kb = 0; kb < k_end; kb += 64) {
         __syncthreads();
-        stage_rows<HD, NT>(kbase, ldk, kb, 64, T, k_row, RS, k_tr, TS, tid);
-        stage_rows<HD, NT>(vbase, ldv, kb, 64, T, v_row, RS, nullptr, 0, tid);
+        store_rows<HD, NT, 64>(kr, k_row, RS, k_tr, TS, tid);
+        store_rows<HD, NT, 64>(vr, v_row, RS, nullptr, 0, tid);
         __syncthreads();
+        if (kb + 64 < k_end) {
+            load_rows<HD, NT, 64>(kr, kbase, ldk, kb + 64, T, tid);
+            load_rows<HD, NT, 64>(vr, vbase, ldv, kb + 64, T, tid);
+        }
         if (!wave_active || kb > wave_kmax) continue;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
@@ -179,16 +200,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_mfma(const bf16* __restr
     const float* lrow = lse + ((long)b * H + hh) * T;
     const float* drow = delta + ((long)b * H + hh) * T;
 
+    RowRegs<HD, NT, 32> qr, dr;
+    float lreg = 0.f, dreg = 0.f;
+    auto fetch = [&](int qb0) {
+        load_rows<HD, NT, 32>(qr, qbase, ldq, qb0, T, tid);
+        load_rows<HD, NT, 32>(dr, dobase, lddo, qb0, T, tid);
+        if (tid < 32) {
+            const int qi = qb0 + tid;
+            lreg = qi < T ? lrow[qi] * 1.4426950408889634f : 0.f;
+            dreg = qi < T ? drow[qi] : 0.f;
+        }
+    };
+    if (q_begin < T) fetch(q_begin);
     for (int qb = q_begin; qb < T; qb += 32) {
         __syncthreads();
-        stage_rows<HD, NT>(qbase, ldq, qb, 32, T, q_row, RS, q_tr, TS, tid);
-        stage_rows<HD, NT>(dobase, lddo, qb, 32, T, do_row, RS, do_tr, TS, tid);
-        if (tid < 32) {
-            const int qi = qb + tid;
-            lse_s[tid] = qi < T ? lrow[qi] * 1.4426950408889634f : 0.f;
-            dlt_s[tid] = qi < T ? drow[qi] : 0.f;
-        }
+        store_rows<HD, NT, 32>(qr, q_row, RS, q_tr, TS, tid);
+        store_rows<HD, NT, 32>(dr, do_row, RS, do_tr, TS, tid);
+        if (tid < 32) { lse_s[tid] = lreg; dlt_s[tid] = dreg; }
         __syncthreads();
+        if (qb + 32 < T) fetch(qb + 32);
         if (!wave_active || (CAUSAL && qb + 31 < k0)) continue;       // every query of this tile precedes the wave's keys
         f32x16 s, dp;
 #pragma unroll

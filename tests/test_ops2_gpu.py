@@ -101,3 +101,34 @@ def test_gemm_small_m_decode_path(dev, M):
     rows = rnd(4 * M, K, dtype=torch.bfloat16, seed=56)          # strided rows (last position of each sequence)
     o = ops.gemm(rows[3::4], B, out_f32=True)
     close(o, rows[3::4].float() @ B.float().t(), 0.05, 1e-2, "small-M gemm strided A")
+
+
+def test_gemm_16wave_narrow_and_wide_epilogues(dev):
+    """The 256x256 kernel's two epilogues: N % 8 != 0 or unaligned pointers take the per-lane path, everything else the
+    LDS-staged 16-byte path; both with row remap / broadcast residual / in-place residual / f32 output."""
+    from avllm import lib as L
+    lib = L.load()
+    try:
+        lib.avllm_set_gemm_variant(5)
+        M, K = 900, 128
+        for N in (516, 520):                                   # narrow, wide
+            A, B = rnd(M, K, dtype=torch.bfloat16, seed=61), rnd(N, K, dtype=torch.bfloat16, seed=62)
+            bias = rnd(N, dtype=torch.bfloat16, seed=63)
+            x = rnd(M, N, dtype=torch.bfloat16, seed=64)
+            ref = (A.float() @ B.float().t() + bias.float()) * 1.0 + x.float()
+            out = x.clone()
+            ops.gemm(A, B, out=out, bias=bias, R=out)          # in-place residual
+            close(out, ref, 0.15, 2e-2, f"in-place residual N={N}")
+            o32 = ops.gemm(A, B, bias=bias, out_f32=True, act=L.ACT_QUICK_GELU)
+            r = A.float() @ B.float().t() + bias.float()
+            close(o32, r * torch.sigmoid(1.702 * r), 0.05, 1e-2, f"f32 out quick_gelu N={N}")
+        N = 256
+        A, B = rnd(M, K, dtype=torch.bfloat16, seed=65), rnd(N, K, dtype=torch.bfloat16, seed=66)
+        pos = rnd(9, N, dtype=torch.bfloat16, seed=67)
+        out = torch.zeros(100 * 10, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(A, B, out=out, R=pos, r_mod=9, remap=(9, 10, 1), M=900)
+        ref = (A.float() @ B.float().t()).view(100, 9, N) + pos.float()
+        close(out.view(100, 10, N)[:, 1:], ref, 0.1, 2e-2, "remap + broadcast residual (wide)")
+        assert out.view(100, 10, N)[:, 0].abs().max().item() == 0
+    finally:
+        lib.avllm_set_gemm_variant(0)
