@@ -38,8 +38,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
     constexpr int VS = HD * 2 + 64;      // V tile row stride (bytes)
     constexpr int CPR = HD / 8;          // 16-byte chunks per row
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char k_lds[64 * KS];
-    __shared__ __attribute__((aligned(16))) char v_lds[64 * VS];
+    // short non-causal sequences (CLIP: 197 tokens, 7 waves): the WHOLE K/V of the (item, head) is staged once (224 rows,
+    // 75 KiB -> two workgroups per CU) and the key loop runs without any further barrier; otherwise 64-key tiles.
+    constexpr bool ONESHOT = (HD == 64 && NW == 7 && !CAUSAL);
+    constexpr int LROWS = ONESHOT ? 224 : 64;
+    __shared__ __attribute__((aligned(16))) char k_lds[LROWS * KS];
+    __shared__ __attribute__((aligned(16))) char v_lds[LROWS * VS];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -87,21 +91,37 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
             }
         }
     };
-    if (PREFETCH) prefetch(0);
-    for (int kb = 0; kb < k_end; kb += 64) {
-        if (!PREFETCH) prefetch(kb);
-        __syncthreads();                       // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * NT;
-            if (c < 64 * CPR) {
-                const int row = c / CPR, ch = c % CPR;
-                *(u32x4*)(k_lds + row * KS + ch * 16) = kreg[i];
-                *(u32x4*)(v_lds + row * VS + ch * 16) = vreg[i];
+    if (ONESHOT) {
+        for (int c = tid; c < LROWS * CPR; c += NT) {
+            const int row = c / CPR, ch = c % CPR;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (row < Tk) {
+                kv = *(const u32x4*)(k + ((long)b * Tk + row) * ldk + (long)hh * HD + ch * 8);
+                vv = *(const u32x4*)(v + ((long)b * Tk + row) * ldv + (long)hh * HD + ch * 8);
             }
+            *(u32x4*)(k_lds + row * KS + ch * 16) = kv;
+            *(u32x4*)(v_lds + row * VS + ch * 16) = vv;
         }
         __syncthreads();
-        if (PREFETCH && kb + 64 < k_end) prefetch(kb + 64);
+    }
+    if (PREFETCH) prefetch(0);
+    for (int kb = 0; kb < k_end; kb += 64) {
+        const int lrow0 = ONESHOT ? kb : 0;        // first LDS row of this 64-key step
+        if (!ONESHOT) {
+            if (!PREFETCH) prefetch(kb);
+            __syncthreads();                       // previous tile fully consumed
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + i * NT;
+                if (c < 64 * CPR) {
+                    const int row = c / CPR, ch = c % CPR;
+                    *(u32x4*)(k_lds + row * KS + ch * 16) = kreg[i];
+                    *(u32x4*)(v_lds + row * VS + ch * 16) = vreg[i];
+                }
+            }
+            __syncthreads();
+            if (PREFETCH && kb + 64 < k_end) prefetch(kb + 64);
+        }
         if (!wave_active || kb > wave_kmax) continue;      // wave-uniform
 
         const bool two = (kb + 32 <= wave_kmax) && (kb + 32 < Tk);   // second 32-key sub-block has visible keys
@@ -110,13 +130,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
         for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
-            const bf16x8 kf0 = *(const bf16x8*)(k_lds + r * KS + (2 * ks + half) * 16);
+            const bf16x8 kf0 = *(const bf16x8*)(k_lds + (lrow0 + r) * KS + (2 * ks + half) * 16);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
         }
         if (two) {
 #pragma unroll
             for (int ks = 0; ks < HD / 16; ++ks) {
-                const bf16x8 kf1 = *(const bf16x8*)(k_lds + (32 + r) * KS + (2 * ks + half) * 16);
+                const bf16x8 kf1 = *(const bf16x8*)(k_lds + (lrow0 + 32 + r) * KS + (2 * ks + half) * 16);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
             }
         }
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
                 bf16x8 pb;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pb[j] = (bf16)(sb == 0 ? s0[8 * s + j] : s1[8 * s + j]);
-                const int krow = 32 * sb + 16 * s + 4 * half + (i16 >> 2);
+                const int krow = lrow0 + 32 * sb + 16 * s + 4 * half + (i16 >> 2);
 #pragma unroll
                 for (int d = 0; d < HD / 32; ++d) {
                     const int col = 32 * d + 16 * (g & 1) + 4 * (i16 & 3);
@@ -216,7 +236,7 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
         return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st);
     if (hd == 64) {
         // short sequences (CLIP: 197 tokens): one workgroup covers the whole sequence with 7 waves
-        if (Tq <= 224 && Tq > 128) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
+        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
         return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
     }
     return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
