@@ -131,7 +131,7 @@ def main():
         frac_e2e = value / world * FLOP_PER_CLIP / MFMA_BF16_PEAK
         if timing and prof[2] > 0:
             ach = prof[1] / (prof[0] * 1e-3) / 1e12           # TFLOP/s over the GEMM launches only
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all dense projections)", "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "mfma", "kernel": "avllm_gemm launches: every dense projection (dominant: gemm_bf16_h_kernel, 256x256 tile, 16 waves)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / (MFMA_BF16_PEAK / 1e12), 4),
                                "traffic": None, "launches_per_step": int(prof[2] / args.steps),
                                "avg_launch_us": round(1000 * prof[0] / prof[2], 2), "gemm_ms_per_step": round(prof[0] / args.steps, 3),
