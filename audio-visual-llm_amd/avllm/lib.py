@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("A2", vp), ("B2", vp), ("C", vp), ("bias", vp), ("R", vp),
                 ("lda", i64), ("ldb", i64), ("lda2", i64), ("ldb2", i64), ("ldc", i64), ("ldr", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("K2", i32), ("dtype", i32), ("out_f32", i32), ("act", i32),
-                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32)]
+                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32), ("a_drop_seed", C.c_uint32), ("a_drop_p", f32)]
 
 
 class EncLayer(C.Structure):
@@ -67,6 +67,7 @@ _SIGS = {
     "avllm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "avllm_set_gemm_variant": ([i32], i32),
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),
+    "avllm_gemm_tn_drop": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, C.c_uint32, f32, i32, vp], i32),
     "avllm_layernorm": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_fwd": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_bwd": ([vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),

@@ -15,8 +15,9 @@ def _ld(t):
 
 
 def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, alpha=1.0, out_f32=False,
-         r_mod=0, remap=None, M=None):
-    """out[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias) + R.  A [M,K] (row stride free), B [N,K]."""
+         r_mod=0, remap=None, M=None, a_drop=None):
+    """out[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias) + R.  A [M,K] (row stride free), B [N,K].
+    a_drop=(seed, p): A is replaced by dropout(A) on the fly (bf16, N == 64 only)."""
     lib = L.load()
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
@@ -36,14 +37,21 @@ def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, al
     d.dtype, d.out_f32, d.act, d.alpha, d.r_mod = dt, int(out_f32), act, alpha, r_mod
     if remap is not None:
         d.g_in, d.g_out, d.g_off = remap
+    if a_drop is not None:
+        d.a_drop_seed, d.a_drop_p = a_drop[0] & 0xFFFFFFFF, a_drop[1]
     L.check(lib.avllm_gemm(C.byref(d), L.stream_ptr()))
     return out
 
 
-def gemm_tn(P, Q, out, I=None, J=None, alpha=1.0):
+def gemm_tn(P, Q, out, I=None, J=None, alpha=1.0, drop=None):
+    """out[I,J] += alpha * P[:, :I]^T . Q[:, :J]; drop=(seed, p) applies dropout to the wide operand on the fly."""
     lib = L.load()
     I = P.shape[1] if I is None else I
     J = Q.shape[1] if J is None else J
+    if drop is not None:
+        L.check(lib.avllm_gemm_tn_drop(L.ptr(P), _ld(P), I, L.ptr(Q), _ld(Q), J, P.shape[0], L.ptr(out), _ld(out), alpha,
+                                       drop[0] & 0xFFFFFFFF, drop[1], L.dt_of(P), L.stream_ptr()))
+        return out
     L.check(lib.avllm_gemm_tn(L.ptr(P), _ld(P), I, L.ptr(Q), _ld(Q), J, P.shape[0], L.ptr(out), _ld(out), alpha,
                               L.dt_of(P), L.stream_ptr()))
     return out

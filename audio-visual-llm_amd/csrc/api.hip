@@ -22,6 +22,8 @@ int avllm_version(void) { return 100; }
 int avllm_gemm(const avllm_gemm_desc* d, void* stream) { return av_gemm(d, ST); }
 int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M, float* out,
                   int64_t ldo, float alpha, int32_t dtype, void* stream) { return av_gemm_tn(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, dtype, ST); }
+int avllm_gemm_tn_drop(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M, float* out,
+                       int64_t ldo, float alpha, uint32_t seed, float p, int32_t dtype, void* stream) { return av_gemm_tn(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, dtype, ST, seed, p); }
 int avllm_layernorm(const void* x, const void* w, const void* b, void* y, int64_t rows, int32_t d, float eps, int32_t dtype,
                     void* stream) { return av_layernorm(x, w, b, y, rows, d, eps, dtype, ST); }
 int avllm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t d, float eps, int32_t dtype,

@@ -5,7 +5,7 @@
 
 int av_gemm(const avllm_gemm_desc* d, hipStream_t st);
 int av_gemm_tn(const void* P, long ldp, int I, const void* Q, long ldq, int J, int M, float* out, long ldo,
-               float alpha, int dtype, hipStream_t st);
+               float alpha, int dtype, hipStream_t st, uint32_t drop_seed = 0, float drop_p = 0.f);
 int av_layernorm(const void* x, const void* w, const void* b, void* y, long rows, int d, float eps, int dtype, hipStream_t st);
 int av_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int d, float eps, int dtype, hipStream_t st);
 int av_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres_in, void* dx_out,

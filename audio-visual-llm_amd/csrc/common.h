@@ -150,14 +150,31 @@ __device__ __forceinline__ float act_apply_fast(float x, int act) {
 }
 
 // Counter-based dropout mask: keep(seed, index) is a pure function, so forward and backward regenerate the same mask
-// instead of storing it.  32-bit avalanche hash (lowbias32) of the element index mixed with the seed.
+// instead of storing it.  One 32-bit avalanche hash (lowbias32) serves TWO neighbouring elements (16 bits each), which keeps
+// the mask cheap enough to be generated inside the rank-side GEMMs; the drop probability is therefore quantised to 1/65536
+// (p = 0.05 -> 3276/65536) and the survivor scale uses that exact value.
 __host__ __device__ __forceinline__ uint32_t av_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+__host__ __device__ __forceinline__ uint32_t av_drop_thr(float p) { return (uint32_t)(p * 65536.0f); }
+__host__ __device__ __forceinline__ float av_drop_scale(float p) { return 1.0f / (1.0f - (float)av_drop_thr(p) * (1.0f / 65536.0f)); }
+// hash word covering elements (2*pair, 2*pair+1)
+__host__ __device__ __forceinline__ uint32_t av_pair_hash(uint32_t seed, unsigned long long pair) {
+    return av_hash32((uint32_t)pair ^ av_hash32(seed + (uint32_t)(pair >> 32) * 0x9E3779B9U));
+}
 __host__ __device__ __forceinline__ bool av_keep(uint32_t seed, unsigned long long idx, float p) {
-    const uint32_t h = av_hash32((uint32_t)idx ^ av_hash32(seed + (uint32_t)(idx >> 32) * 0x9E3779B9U));
-    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+    const uint32_t h = av_pair_hash(seed, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= av_drop_thr(p);
+}
+// mask 8 consecutive elements starting at an EVEN index (4 hashes)
+__device__ __forceinline__ void av_mask8(float (&v)[8], uint32_t seed, unsigned long long idx0, uint32_t thr, float sc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t h = av_pair_hash(seed, (idx0 >> 1) + q);
+        v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * sc : 0.f;
+        v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * sc : 0.f;
+    }
 }
 
 static inline int av_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

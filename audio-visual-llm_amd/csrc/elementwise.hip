@@ -113,7 +113,7 @@ __global__ void swiglu_bwd_kernel(const T* __restrict__ dh, const T* __restrict_
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int d, uint32_t seed, float p) {
     const long total = rows * (d >> 2);
-    const float sc = 1.0f / (1.0f - p);
+    const float sc = av_drop_scale(p);
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         float v[4];
         load_f<4>(x + idx * 4, v);

@@ -167,13 +167,15 @@ int check_llama(const avllm_llama* m) {
 
 // y[:, slice j] = x W_j^T (+ t_j B_j^T)
 int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long ldw, int K, int N, const avllm_lora_mod& lm,
-              void* t, long ldt, void* y, long ldy, const void* R, long ldr, int M, hipStream_t st, const void* xl = nullptr) {
+              void* t, long ldt, void* y, long ldy, const void* R, long ldr, int M, hipStream_t st, const void* xl = nullptr,
+              uint32_t a_seed = 0, float a_p = 0.f) {
     avllm_gemm_desc g;
     const bool has = lm.A_pad != nullptr;
     if (has) {
         // xl = dropout(x) for the adapter branch when lora_dropout is active (peft: lora_B(lora_A(dropout(x))))
         g = gemm_desc(m->dtype, xl ? xl : x, xl ? (long)K : ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
         g.alpha = m->lora_scale;
+        g.a_drop_seed = a_seed; g.a_drop_p = a_p;      // bf16: dropout generated inside the rank-side GEMM
         AV_TRY(av_gemm(&g, st));
     }
     g = gemm_desc(m->dtype, x, ldx, W, ldw, y, ldy, M, N, K);
@@ -277,16 +279,19 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     AV_HIP(hipMemcpyAsync(resid[0], x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
     AV_TRY(av_rope_table(w.rope_tab, S, hd, 0, m->theta, st));
     const bool drop = m->lora_dropout > 0.f;
+    // bf16 (MFMA kernels): masks are generated inside the rank-side GEMMs; fp32 parity mode materialises dropout(x)
+    const bool fuse_drop = drop && m->dtype == AV_BF16 && d % 256 == 0 && m->lora_r <= 16;
     for (int l = 0; l < m->layers; ++l) {
         const avllm_llama_layer& P = m->layer[l];
         LlamaLayerAct& a = act[l];
         AV_TRY(av_rmsnorm_fwd(resid[l], P.ln1_w, a.xn1, a.rstd1, M, d, m->eps, dt, st));
         for (int j = 0; j < 3; ++j) {
             const void* xl = nullptr;
-            if (drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xl = w.xd; }
+            const uint32_t sj = m->dropout_seed + 4u * l + j;
+            if (drop && !fuse_drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, sj, m->lora_dropout, dt, st)); xl = w.xd; }
             AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j],
                              (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
-                             (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st, xl));
+                             (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
         }
         AV_TRY(av_rope_tab(a.qkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 0, dt, st));      // q and k slices are adjacent: 2H heads
         const char* qkv = (const char*)a.qkv;
@@ -294,8 +299,10 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
                                 3 * d, d, 1.0f / sqrtf((float)hd), 1, dt, 0, st));
         {
             const void* xl = nullptr;
-            if (drop && P.lora[3].A_pad) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xl = w.xd; }
-            AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st, xl));
+            const uint32_t so = m->dropout_seed + 4u * l + 3;
+            if (drop && !fuse_drop && P.lora[3].A_pad) { AV_TRY(av_dropout(a.att, w.xd, M, d, so, m->lora_dropout, dt, st)); xl = w.xd; }
+            AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st, xl, so,
+                             fuse_drop ? m->lora_dropout : 0.f));
         }
         AV_TRY(av_rmsnorm_fwd(a.h1, P.ln2_w, w.xn2, a.rstd2, M, d, m->eps, dt, st));
         avllm_gemm_desc g = gemm_desc(dt, w.xn2, d, P.wgu, d, a.gu, 2 * f, M, 2 * f, d);
@@ -329,6 +336,8 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
     const int M = B * S, R = m->lora_r;
     const float sc = m->lora_scale;
     const bool drop = m->lora_dropout > 0.f;
+    // bf16 (MFMA kernels): masks are generated inside the rank-side GEMMs; fp32 parity mode materialises dropout(x)
+    const bool fuse_drop = drop && m->dtype == AV_BF16 && d % 256 == 0 && m->lora_r <= 16;
     AV_TRY(av_ce_bwd(w.logits, V, labels, w.row_lse, count, grad_scale, w.logits, B, S, V, dt, st));
     avllm_gemm_desc g = gemm_desc(dt, w.logits, V, m->lm_head_t, V, w.dxn, d, M, d, V);
     AV_CHECK_ARG(V % 64 == 0, "llama_lora_bwd: vocab %d must be a multiple of 64", V);
@@ -354,8 +363,9 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             gt.alpha = sc;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.att;
-            if (drop) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xin = w.xd; }
-            AV_TRY(av_gemm_tn(w.dto, AVLLM_LORA_PAD, R, xin, d, d, M, lo.gA, d, 1.0f, dt, st));
+            if (drop && !fuse_drop) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xin = w.xd; }
+            AV_TRY(av_gemm_tn(w.dto, AVLLM_LORA_PAD, R, xin, d, d, M, lo.gA, d, 1.0f, dt, st, m->dropout_seed + 4u * l + 3,
+                              fuse_drop ? m->lora_dropout : 0.f));
             if (!drop) { g.A2 = w.dto; g.lda2 = AVLLM_LORA_PAD; g.B2 = lo.AT_pad; g.ldb2 = lo.ld_at; g.K2 = AVLLM_LORA_PAD; }
         }
         AV_TRY(av_gemm(&g, st));
@@ -384,8 +394,9 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             gt.alpha = sc;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.xn1;
-            if (drop) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xin = w.xd; }
-            AV_TRY(av_gemm_tn(dtj, 3 * AVLLM_LORA_PAD, R, xin, d, d, M, lj.gA, d, 1.0f, dt, st));
+            if (drop && !fuse_drop) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xin = w.xd; }
+            AV_TRY(av_gemm_tn(dtj, 3 * AVLLM_LORA_PAD, R, xin, d, d, M, lj.gA, d, 1.0f, dt, st, m->dropout_seed + 4u * l + j,
+                              fuse_drop ? m->lora_dropout : 0.f));
             if (lj.ld_at != 3 * AVLLM_LORA_PAD ||
                 (const char*)lj.AT_pad != (const char*)P.lora[0].AT_pad + (size_t)j * AVLLM_LORA_PAD * es) contiguous = false;
         }

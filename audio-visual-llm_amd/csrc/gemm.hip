@@ -43,7 +43,7 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& e, int m, int n
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i] * e.alpha + b[i], e.act);
     if (e.drop_p > 0.f) {
-        const float sc = 1.0f / (1.0f - e.drop_p);
+        const float sc = av_drop_scale(e.drop_p);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = av_keep(e.drop_seed, (unsigned long long)m * e.N + n0 + i, e.drop_p) ? v[i] * sc : 0.f;
     }
@@ -83,9 +83,7 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n
         for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], e.act);
     }
     if (e.drop_p > 0.f) {
-        const float sc = 1.0f / (1.0f - e.drop_p);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = av_keep(e.drop_seed, (unsigned long long)m * e.N + n0 + i, e.drop_p) ? v[i] * sc : 0.f;
+        av_mask8(v, e.drop_seed, (unsigned long long)m * e.N + n0, av_drop_thr(e.drop_p), av_drop_scale(e.drop_p));      // N % 8 == 0: even start
     }
     if (e.R) {
         const long rr = e.r_mod > 0 ? (m % e.r_mod) : m;
@@ -503,9 +501,23 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_hp_kernel(GemmArgs g) {
 // M=2048, K=4096).  Here a workgroup owns 16 rows and splits K over its 8 waves (split-K inside the block, reduced
 // through LDS), operands go straight from global/L2 to MFMA fragments (no reuse to stage for: A is read once).
 constexpr int SK_WAVES = 8;
+__device__ __forceinline__ bf16x8 drop_frag(bf16x8 x, uint32_t seed, unsigned long long idx0, uint32_t thr, float sc) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    av_mask8(v, seed, idx0, thr, sc);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16)v[j];
+    return r;
+}
+
+// DROP: the A operand is dropout(A) with the library's counter-based mask over the logical index row*K + col (A must be the
+// full [M,K] activation) -- peft's lora_A(dropout(x)) without materialising dropout(x).
+template <bool DROP>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B,
                                                                       long ldb, int M, int K, float alpha, void* __restrict__ C, long ldc,
-                                                                      int out_f32) {
+                                                                      int out_f32, uint32_t seed, float p) {
     __shared__ float part[SK_WAVES][16][65];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -517,13 +529,33 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = 0; k < kw; k += 32) {
-        const bf16x8 xa = *(const bf16x8*)(ap + k);
+    // explicit 4-deep software unroll (the pragma form is rejected for the runtime trip count): 20 independent 16-byte loads
+    // are issued before the first MFMA of a group consumes one, which is what hides the HBM/L2 latency here
+    const uint32_t thr = av_drop_thr(p);
+    const float dsc = av_drop_scale(p);
+    const unsigned long long idx_base = (unsigned long long)ar * K + (unsigned long long)w * kw + fq * 8;
+    int k = 0;
+    for (; k + 128 <= kw; k += 128) {
+        bf16x8 xa[4], wb[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xa[u] = *(const bf16x8*)(ap + k + 32 * u);
+            if (DROP) xa[u] = drop_frag(xa[u], seed, idx_base + k + 32 * u, thr, dsc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wb[u][j] = *(const bf16x8*)(bp + (long)j * 16 * ldb + k + 32 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u][j], xa[u], acc[j], 0, 0, 0);     // D[n][m]
+    }
+    for (; k < kw; k += 32) {
+        bf16x8 xa = *(const bf16x8*)(ap + k);
+        if (DROP) xa = drop_frag(xa, seed, idx_base + k, thr, dsc);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16x8 wb = *(const bf16x8*)(bp + (long)j * 16 * ldb + k);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc[j], 0, 0, 0);     // D[n][m]
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc[j], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -559,12 +591,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_smallm_kernel(GemmArgs g) 
     const bf16* ap = g.A + (long)ar * g.lda + (long)w * kw + fq * 8;
     const bf16* bp = g.B + (long)(n0 + fr) * g.ldb + (long)w * kw + fq * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int k = 0; k < kw; k += 32) {
-        const bf16x8 wb = *(const bf16x8*)(bp + k);
-        const bf16x8 xa = *(const bf16x8*)(ap + k);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc, 0, 0, 0);          // D[n][m]
+    int k = 0;
+    for (; k + 256 <= kw; k += 256) {          // explicit 8-deep unroll: 16 loads (16 KiB per wave) in flight
+        bf16x8 wb[8], xa[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { wb[u] = *(const bf16x8*)(bp + k + 32 * u); xa[u] = *(const bf16x8*)(ap + k + 32 * u); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xa[u], acc, 0, 0, 0);          // D[n][m]
     }
+    for (; k < kw; k += 32)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(bp + k), *(const bf16x8*)(ap + k), acc, 0, 0, 0);
     if (w == 0 && g.K2 > 0) {
         const bf16* ap2 = g.A2 + (long)ar * g.lda2 + fq * 8;
         const bf16* bp2 = g.B2 + (long)(n0 + fr) * g.ldb2 + fq * 8;
@@ -686,9 +722,16 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         g.wide_epi = wide_ok;
         hipLaunchKernelGGL(gemm_smallm_kernel, dim3(d->N / 16), dim3(SK_WAVES * 64), 0, st, g);
     } else if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
-        d->K % (32 * SK_WAVES) == 0 && d->M >= 256) {
-        hipLaunchKernelGGL(gemm_skinny64_kernel, dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
-                           (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32);
+               d->K % (32 * SK_WAVES) == 0 && (d->M >= 256 || d->a_drop_p > 0.f)) {
+        AV_CHECK_ARG(d->a_drop_p <= 0.f || d->lda == d->K, "gemm: a_drop needs the full contiguous [M,K] activation as A");
+        if (d->a_drop_p > 0.f)
+            hipLaunchKernelGGL((gemm_skinny64_kernel<true>), dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
+                               (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, d->a_drop_seed, d->a_drop_p);
+        else
+            hipLaunchKernelGGL((gemm_skinny64_kernel<false>), dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
+                               (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, 0u, 0.f);
+    } else if (d->a_drop_p > 0.f) {
+        return av_set_error(AV_ERR_UNSUPPORTED, "gemm: a_drop_p is only implemented by the bf16 N==64 rank-side kernel (K %% 256 == 0)");
     } else if (d->dtype == AV_BF16) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;

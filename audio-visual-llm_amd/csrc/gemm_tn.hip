@@ -28,7 +28,7 @@ constexpr int SM_STRIDE = 48;                 // 16 bf16 + pad
 template <bool TRANS_OUT>
 __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restrict__ Big, long ldb, const bf16* __restrict__ Small,
                                                            long lds_, int R, int M, int mchunk, float* __restrict__ out, long ldo,
-                                                           float alpha) {
+                                                           float alpha, int NB, uint32_t drop_seed, float drop_p) {
     __shared__ __attribute__((aligned(16))) char big_s[TN_M * BIG_STRIDE];
     __shared__ __attribute__((aligned(16))) char small_s[TN_M * SM_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -43,6 +43,17 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
             const int row = c >> 4, ch = c & 15;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (mb + row < m_end) v = *(const u32x4*)(Big + (long)(mb + row) * ldb + n0 + ch * 8);
+            if (drop_p > 0.f) {          // Big = dropout(x): regenerate the forward's mask (index row*NB + col) instead of reading a copy
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, v);
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (float)xb[j];
+                av_mask8(f, drop_seed, (unsigned long long)(mb + row) * NB + n0 + ch * 8, av_drop_thr(drop_p), av_drop_scale(drop_p));
+                bf16x8 yb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yb[j] = (bf16)f[j];
+                v = __builtin_bit_cast(u32x4, yb);
+            }
             *(u32x4*)(big_s + row * BIG_STRIDE + ch * 16) = v;
         }
         if (tid < TN_M * 2) {
@@ -81,15 +92,15 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
 
 // Big [M,NB] (NB % 128 == 0), Small [M,>=16 cols, R valid]; out [NB,R] (TRANS_OUT=0) or [R,NB] (TRANS_OUT=1)
 int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
-                    int trans_out, hipStream_t st) {
+                    int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p) {
     int zs = av_cdiv(M, 256);
     zs = zs > 32 ? 32 : zs;
     int mchunk = av_cdiv(M, zs);
     mchunk = (mchunk + TN_M - 1) / TN_M * TN_M;
     zs = av_cdiv(M, mchunk);
     const dim3 grid(NB / TN_N, zs);
-    if (trans_out) hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha);
-    else hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha);
+    if (trans_out) hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha, NB, drop_seed, drop_p);
+    else hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha, NB, drop_seed, drop_p);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

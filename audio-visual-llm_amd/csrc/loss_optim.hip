@@ -5,7 +5,7 @@
 #include "avllm_internal.h"
 
 int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
-                    int trans_out, hipStream_t st);
+                    int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p);
 
 namespace {
 
@@ -226,12 +226,13 @@ int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr
 }
 
 int av_gemm_tn(const void* P, long ldp, int I, const void* Q, long ldq, int J, int M, float* out, long ldo,
-               float alpha, int dtype, hipStream_t st) {
+               float alpha, int dtype, hipStream_t st, uint32_t drop_seed, float drop_p) {
     AV_CHECK_ARG(P && Q && out && I > 0 && J > 0 && M > 0, "gemm_tn: bad args");
     if (dtype == AV_BF16 && ldp % 8 == 0 && ldq % 8 == 0) {
-        if (J <= 16 && I % 128 == 0) return av_gemm_tn_mfma(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, 0, st);
-        if (I <= 16 && J % 128 == 0) return av_gemm_tn_mfma(Q, ldq, J, P, ldp, I, M, out, ldo, alpha, 1, st);
+        if (J <= 16 && I % 128 == 0) return av_gemm_tn_mfma(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, 0, st, drop_seed, drop_p);
+        if (I <= 16 && J % 128 == 0) return av_gemm_tn_mfma(Q, ldq, J, P, ldp, I, M, out, ldo, alpha, 1, st, drop_seed, drop_p);
     }
+    if (drop_p > 0.f) return av_set_error(AV_ERR_UNSUPPORTED, "gemm_tn: on-the-fly dropout needs the bf16 MFMA path (rank <= 16, width %% 128 == 0)");
     int zs = av_cdiv(M, 256);
     zs = zs > 32 ? 32 : zs;
     int mchunk = av_cdiv(M, zs);

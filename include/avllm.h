@@ -52,6 +52,8 @@ typedef struct avllm_gemm_desc {
     int32_t g_in, g_out, g_off;         /* g_in>0: output row = (m/g_in)*g_out + g_off + m%g_in */
     uint32_t drop_seed;                 /* drop_p>0: the product (before +R) is multiplied by the dropout mask */
     float drop_p;                       /*   keep(drop_seed, m*N+n, p)/(1-p)  -- see avllm_dropout */
+    uint32_t a_drop_seed;               /* a_drop_p>0: the A operand is dropout(A), mask index m*K+k (bf16, N==64 rank-side GEMM only): */
+    float a_drop_p;                     /*   peft's lora_A(dropout(x)) without materialising dropout(x) */
 } avllm_gemm_desc;
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
 /* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT) */
@@ -60,6 +62,9 @@ int avllm_set_gemm_variant(int v);
 /* out[I,J] (f32, row stride ldo) += alpha * sum_m P[m,i]*Q[m,j]; LoRA dA/dB (autograd of peft lora.Linear) */
 int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
                   float* out, int64_t ldo, float alpha, int32_t dtype, void* stream);
+/* same, with dropout(seed,p) applied on the fly to the WIDE operand (mask index m*width+col; bf16 MFMA path only) */
+int avllm_gemm_tn_drop(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
+                       float* out, int64_t ldo, float alpha, uint32_t drop_seed, float drop_p, int32_t dtype, void* stream);
 
 /* nn.LayerNorm (HF whisper :379-413, clip :362-384) */
 int avllm_layernorm(const void* x, const void* w, const void* b, void* y, int64_t rows, int32_t d, float eps,

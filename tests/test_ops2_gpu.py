@@ -37,6 +37,30 @@ def test_gemm_tn_mfma(dev, M, NB):
     close(out_t, 4 * ref.t(), 8e-3 * (M ** 0.5), 1e-3, "gemm_tn accumulate")
 
 
+@pytest.mark.parametrize("M,K", [(4096, 4096), (300, 512), (17, 256)])
+def test_fused_dropout_equals_materialised(dev, M, K):
+    """The rank-side GEMM and the dA reduction regenerate the dropout mask in-kernel: same result as running them on
+    avllm_dropout's output (peft lora.Linear: lora_A(dropout(x)), clip_whisper_model.py:961-1005)."""
+    seed, p = 1234, 0.05
+    x = rnd(M, K, dtype=torch.bfloat16, seed=21)
+    A = rnd(64, K, dtype=torch.bfloat16, seed=22)
+    xd = ops.dropout(x, seed, p)
+    frac = (xd == 0).float().mean().item()
+    assert abs(frac - p) < 0.01 + 3 * (p / (M * K)) ** 0.5, frac
+    t_ref = ops.gemm(xd, A, alpha=2.0)
+    t = ops.gemm(x, A, alpha=2.0, a_drop=(seed, p))
+    assert torch.equal(t, t_ref)                               # identical kernel and operand bits
+    dt = rnd(M, 64, dtype=torch.bfloat16, seed=23)
+    if K % 128 == 0:
+        g_ref = torch.zeros(16, K, device=dev)
+        ops.gemm_tn(dt, xd, g_ref, I=16)
+        g = torch.zeros(16, K, device=dev)
+        ops.gemm_tn(dt, x, g, I=16, drop=(seed, p))
+        close(g, g_ref, 1e-3 * (M ** 0.5), 1e-4, "gemm_tn fused dropout")     # fp32 atomics: order only
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, rnd(128, K, dtype=torch.bfloat16, seed=24), a_drop=(seed, p))      # only the N == 64 kernel implements it
+
+
 def test_gemm_full_size_llama_shapes(dev):
     """Llama-2-7B projection shapes at the bench batch (M = 8*256): against torch.matmul on the device."""
     M = 2048
