@@ -6,13 +6,15 @@ sys.path.insert(0, os.path.join(ROOT, "audio-visual-llm_amd"))
 import torch
 from avllm import ops, lib as L
 
+MB = int(os.environ.get("ROWS", "4096"))       # B*S of the bench batch (16 x 256)
 SHAPES = [  # (M, N, K, tag)
-    (2048, 4096, 4096, "llama q/k/v/o"), (2048, 12288, 4096, "llama qkv fused"), (2048, 22016, 4096, "llama gate+up"),
-    (2048, 4096, 11008, "llama down"), (2048, 4096, 22016, "llama d(gate,up)"), (2048, 11008, 4096, "llama d(down)"),
-    (2048, 32000, 4096, "lm_head"), (4096, 4096, 4096, "llama o B=16"),
-    (197000, 2304, 768, "clip qkv"), (197000, 768, 768, "clip out"), (197000, 3072, 768, "clip fc1"), (197000, 768, 3072, "clip fc2"),
-    (12000, 2304, 768, "whisper qkv"), (12000, 3072, 768, "whisper fc1"), (12000, 768, 3072, "whisper fc2"),
+    (MB, 4096, 4096, "llama q/k/v/o"), (MB, 12288, 4096, "llama qkv fused"), (MB, 22016, 4096, "llama gate+up"),
+    (MB, 4096, 11008, "llama down"), (MB, 4096, 22016, "llama d(gate,up)"), (MB, 11008, 4096, "llama d(down)"),
+    (MB, 32000, 4096, "lm_head"), (MB, 4096, 32000, "d(lm_head)"),
+    (394000, 2304, 768, "clip qkv"), (394000, 768, 768, "clip out"), (394000, 3072, 768, "clip fc1"), (394000, 768, 3072, "clip fc2"),
+    (24000, 2304, 768, "whisper qkv"), (24000, 3072, 768, "whisper fc1"), (24000, 768, 3072, "whisper fc2"),
 ]
+CALIBRATE = os.environ.get("CALIBRATE", "0") == "1"     # also time torch.matmul (hipBLASLt) on the same operands: a yardstick only
 
 def main():
     dev = "cuda"
@@ -32,7 +34,18 @@ def main():
             ops.gemm(A, B, out=out, bias=bias, act=act)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        print(f"{tag:18s} M={M:6d} N={N:5d} K={K:5d}  {ms*1000:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s", flush=True)
+        extra = ""
+        if CALIBRATE and not act:
+            Bt = B.t()
+            for _ in range(3):
+                torch.matmul(A, Bt, out=out)
+            e0.record()
+            for _ in range(n):
+                torch.matmul(A, Bt, out=out)
+            e1.record(); torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1) / n
+            extra = f"   | hipBLASLt {ms2*1000:9.1f} us {2*M*N*K/ms2/1e9:8.1f} TF/s"
+        print(f"{tag:18s} M={M:6d} N={N:5d} K={K:5d}  {ms*1000:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s{extra}", flush=True)
 
 if __name__ == "__main__":
     main()
