@@ -1,0 +1,110 @@
+"""Edge cases of the hot path on the GPU against the CPU oracle on the same seeded inputs (fp32 mode, so the bar is the
+north-star one: logits within 1e-3, loss within 1e-4, LoRA gradients within 2e-4 relative, greedy tokens identical).
+Covers what ClipWhisperModel.forward/encode/generate branch on (clip_whisper_model.py:407-462, :577-598, :621-736,
+:1280-1294): single-modality inputs, sequences shorter and longer than the label length (linear interpolation with
+align_corners / adaptive average pooling), no prompt, over-long prompt, B=1 and one frame, rows with no valid label."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import avsr_oracle as O  # noqa: E402
+from oracle import weights as Wt  # noqa: E402
+from test_model_gpu import make_model  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def setup():
+    oc = Wt.tiny()
+    W = Wt.all_weights(oc, 11, lora_b_std=0.05)
+    return oc, W
+
+
+def batch(oc, B, frames, seed, prompt_len=50):
+    audio, video, labels, _ = Wt.synthetic_batch(oc, B, frames, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    prompt = torch.randint(3, oc.llama.vocab, (B, prompt_len), generator=g)
+    return audio, video, labels, prompt
+
+
+def check_train(dev, oc, W, m, audio, video, prompt, labels, max_seq_len):
+    cfg = copy.copy(oc)
+    cfg.max_seq_len = max_seq_len
+    ref_loss, ref_logits, ref_grads = O.train_step_grads(W, cfg, audio, video, prompt, labels)
+    m.train()
+    to = lambda t: None if t is None else t.to(dev)
+    out = m(audio=to(audio), video=to(video), prompt=to(prompt), labels=to(labels))
+    assert out["logits"].shape == ref_logits.shape
+    dl = (out["logits"].float().cpu() - ref_logits).abs().max().item()
+    assert dl < 1e-3, dl
+    assert abs(float(out["loss"].detach()) - float(ref_loss)) < 1e-4
+    m.lora_param.grad = None
+    out["loss"].backward()
+    for k, gr in m.llm_engine.lora_views(m.lora_param.grad).items():
+        ref = ref_grads[k]
+        assert (gr.cpu() - ref).abs().max() <= 2e-4 * max(1e-3, float(ref.abs().max())) + 1e-7, (k, (gr.cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("max_seq_len,frames", [(64, 5), (1536, 7), (224, 300)])
+def test_both_modalities_short_and_long_sequences(dev, setup, max_seq_len, frames):
+    """P+L = 96 (interpolated up to the 256 labels), 1532 (pooled down), and the no-op case P+L = 256 with more video
+    frames than the cap (300 > 224: video truncated, audio truncated)."""
+    oc, W = setup
+    audio, video, labels, prompt = batch(oc, 2, frames, seed=5)
+    m = make_model(oc, W, "fp32", max_seq_len=max_seq_len)
+    check_train(dev, oc, W, m, audio, video, prompt, labels, max_seq_len)
+
+
+def test_audio_only_and_video_only_training(dev, setup):
+    oc, W = setup
+    audio, video, labels, prompt = batch(oc, 2, 9, seed=6)
+    m = make_model(oc, W, "fp32")
+    m.modality = "audio"                                  # 1500 frames + prompt -> pooled to 256 (no max_seq_len cap, :428-437)
+    check_train(dev, oc, W, m, audio, None, prompt, labels, 512)
+    m.modality = "video"                                  # 9 frames + 32 prompt tokens = 41 -> interpolated to 256
+    check_train(dev, oc, W, m, None, video, prompt, labels, 512)
+    m.modality = "both"                                   # modality "both" with one input missing falls back to the other (:438-444)
+    check_train(dev, oc, W, m, audio, None, prompt, labels, 512)
+
+
+def test_no_prompt_single_clip_single_frame(dev, setup):
+    oc, W = setup
+    audio, video, labels, prompt = batch(oc, 1, 1, seed=7)
+    m = make_model(oc, W, "fp32")
+    check_train(dev, oc, W, m, audio, video, None, labels, 512)
+    check_train(dev, oc, W, m, audio, video, prompt[:, :3], labels, 512)          # 3-token prompt: P+L = 515 -> pooled
+
+
+def test_rows_without_valid_labels_and_full_rows(dev, setup):
+    """Row 0 all pad (contributes nothing), row 1 no pad at all, row 2 ordinary: the mean runs over valid targets only."""
+    oc, W = setup
+    audio, video, labels, prompt = batch(oc, 3, 4, seed=8)
+    labels[0, :] = oc.pad_token_id
+    g = torch.Generator().manual_seed(3)
+    labels[1, :] = torch.randint(3, oc.llama.vocab, (labels.shape[1],), generator=g)
+    m = make_model(oc, W, "fp32")
+    check_train(dev, oc, W, m, audio, video, prompt, labels, 512)
+
+
+def test_eval_forward_and_generate_single_modality(dev, setup):
+    oc, W = setup
+    audio, video, labels, prompt = batch(oc, 2, 6, seed=9)
+    m = make_model(oc, W, "fp32").eval()
+    cfg = copy.copy(oc)
+    # eval: labels padded with -100 up to P+L (video only: 6 + 32 = 38 < 256 -> labels truncated instead, :586-598)
+    ref = O.forward(W, cfg, None, video, prompt, labels, training=False)
+    m.modality = "video"
+    out = m(audio=None, video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    assert out["logits"].shape == ref["logits"].shape == (2, 38, oc.llama.vocab)
+    assert (out["logits"].float().cpu() - ref["logits"]).abs().max() < 1e-3
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    toks = m.generate(video=video.to(dev), prompt=prompt.to(dev), max_new_tokens=6)
+    ref_t = O.generate(W, cfg, None, video, prompt, max_new_tokens=6)
+    assert torch.equal(toks.cpu(), ref_t)
+    m.modality = "both"
+    toks = m.generate(audio=audio.to(dev), prompt=None, max_new_tokens=4)          # generate() switches modality by its inputs (:1280-1294)
+    ref_t = O.generate(W, cfg, audio, None, None, max_new_tokens=4)
+    assert torch.equal(toks.cpu(), ref_t)
+    assert m.modality == "both"
