@@ -47,6 +47,22 @@ def synthetic_batch(cfg, B, frames, seed, device):
     return audio, video, labels, labels[:, :32].clone()
 
 
+PMC_SUMMARY = "profiles/r01_pmc_hbm_summary_b16.txt"
+
+
+def pmc_traffic_bytes():
+    """PMC counters need their own rocprofv3 passes (no --pmc next to timing), so the per-launch HBM traffic of the dominant
+    kernel is read from the committed summary of that pass (tools/pmc_summary.py); None when the file is absent."""
+    try:
+        for line in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)):
+            f = line.split()
+            if f and f[0] == "gemm_bf16_h_kernel":
+                return round((float(f[2]) + float(f[3])) * 2 ** 20)
+    except OSError:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,7 +149,8 @@ def main():
             ach = prof[1] / (prof[0] * 1e-3) / 1e12           # TFLOP/s over the GEMM launches only
             out["roofline"] = {"bound": "mfma", "kernel": "avllm_gemm launches: every dense projection (dominant: gemm_bf16_h_kernel, 256x256 tile, 16 waves)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / (MFMA_BF16_PEAK / 1e12), 4),
-                               "traffic": None, "launches_per_step": int(prof[2] / args.steps),
+                               "traffic": pmc_traffic_bytes(), "traffic_note": "HBM bytes per gemm_bf16_h_kernel launch (FETCH_SIZE x2-corrected + WRITE_SIZE) from the separate rocprofv3 --pmc pass summarised in " + PMC_SUMMARY,
+                               "launches_per_step": int(prof[2] / args.steps),
                                "avg_launch_us": round(1000 * prof[0] / prof[2], 2), "gemm_ms_per_step": round(prof[0] / args.steps, 3),
                                "gemm_tflop_per_step": round(prof[1] / args.steps / 1e12, 3),
                                "end_to_end_frac": round(frac_e2e, 4)}
