@@ -68,6 +68,14 @@ _SIGS = {
     "avllm_set_gemm_variant": ([i32], i32),
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),
     "avllm_gemm_tn_drop": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, C.c_uint32, f32, i32, vp], i32),
+    "avllm_logmel_table_bytes": ([], C.c_size_t),
+    "avllm_logmel_table_init": ([vp], i32),
+    "avllm_logmel_workspace_bytes": ([i32], C.c_size_t),
+    "avllm_logmel": ([vp, vp, i32, i32, i64, i32, vp, vp, C.c_size_t, vp], i32),
+    "avllm_clip_preproc_plan_bytes": ([i32, i32, i32], C.c_size_t),
+    "avllm_clip_preproc_plan_init": ([vp, i32, i32, i32, vp, vp], i32),
+    "avllm_clip_preproc_workspace_bytes": ([i32, i32, i32, i32], C.c_size_t),
+    "avllm_clip_preproc": ([vp, vp, i32, i32, i32, i32, vp, i32, vp, C.c_size_t, vp], i32),
     "avllm_layernorm": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_fwd": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_bwd": ([vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),

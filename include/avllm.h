@@ -138,6 +138,33 @@ int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,
                     int64_t ld_at, void* B_pad, void* BT_pad, int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------- input features on device ----------------
+ * The reference builds the hot path's inputs on CPU workers, one sample at a time (src/clip_whisper/data/simple_dataset.py):
+ *   audio :156-186  whisper_processor(audio, sampling_rate=16000).input_features then F.layer_norm(features, features.shape)
+ *   video :191-264  clip_processor(images=frame)["pixel_values"] per RGB uint8 frame
+ * These entry points do the same arithmetic on the GPU from the raw samples / raw uint8 frames (4x fewer PCIe bytes for
+ * video than fp32 pixel_values).  Tables/plans are small device buffers the caller allocates and initialises once
+ * (synchronous copy); the compute calls only enqueue kernels. */
+
+/* Whisper log-mel: wave f32 [B, n] (row stride ld, mono 16 kHz, rows zero-padded to n; n > 480000 is truncated) ->
+ * out f32 [B,80,3000]: 30 s zero pad, reflect pad 200, Hann(400) hop 160, |DFT|^2 (float64), slaney mel 80, log10, clamp to
+ * max-8, (x+4)/4 (WhisperFeatureExtractor, feature_extraction_whisper.py:105-133); normalize != 0 adds the dataset's
+ * whole-tensor layer norm (simple_dataset.py:181-183). */
+size_t avllm_logmel_table_bytes(void);
+int avllm_logmel_table_init(void* table_dev);
+size_t avllm_logmel_workspace_bytes(int32_t B);
+int avllm_logmel(const void* table, const float* wave, int32_t B, int32_t n, int64_t ld, int32_t normalize, float* out,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* CLIPImageProcessor on device: frames u8 [N,H,W,3] RGB -> out [N,3,image,image] (dtype f32 or bf16): resize so the shorter
+ * edge is `image` (Pillow BICUBIC, bit-exact 8-bit fixed point: horizontal pass, uint8, vertical pass), centre crop, x/255,
+ * (x-mean)/std.  A plan is specific to (H, W, image, mean, std). */
+size_t avllm_clip_preproc_plan_bytes(int32_t H, int32_t W, int32_t image);
+int avllm_clip_preproc_plan_init(void* plan_dev, int32_t H, int32_t W, int32_t image, const float* mean3, const float* std3);
+size_t avllm_clip_preproc_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t image);
+int avllm_clip_preproc(const void* plan, const uint8_t* frames, int32_t N, int32_t H, int32_t W, int32_t image, void* out,
+                       int32_t dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* Live kernel timing for bench.py: between begin and end every avllm_gemm launch (direct or inside the model-level
  * calls) is bracketed by two HIP events on its stream.  out[0]=sum of GEMM ms, out[1]=sum of algorithmic FLOPs
  * (2*M*N*(K+K2)), out[2]=launches timed. */
