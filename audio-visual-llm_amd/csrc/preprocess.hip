@@ -152,8 +152,53 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const char* __restrict__ 
     o[0] = (unsigned char)clip8(s0); o[1] = (unsigned char)clip8(s1); o[2] = (unsigned char)clip8(s2);
 }
 
-// vertical pass + rescale/normalize (256-entry table per channel): tmp [N,H,image,3] -> out [N,3,image,image]
-template <typename T>
+// horizontal pass, staged: a workgroup copies RPB whole input rows (contiguous bytes in [N*H, W*3]) into LDS with aligned dword
+// loads, then each thread produces 4 adjacent output pixels (12 bytes, three dword stores) from LDS bytes.  Needs image % 4 == 0.
+__global__ __launch_bounds__(256) void resize_h4_kernel(const char* __restrict__ plan, const unsigned char* __restrict__ in,
+                                                        unsigned char* __restrict__ tmp, long rows_total, long in_bytes, int rpb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rows_s[];
+    const ResizeHdr* h = (const ResizeHdr*)plan;
+    const int* bx = (const int*)(plan + h->off_bx);
+    const int* kx = (const int*)(plan + h->off_kx);
+    const int S = h->image, SV = S >> 2, W3 = h->W * 3, ksx = h->ksx;
+    const long row0 = (long)blockIdx.x * rpb;
+    const int nrows = (int)(rows_total - row0 < rpb ? rows_total - row0 : rpb);
+    const long a0 = row0 * W3, a_al = a0 & ~3L;
+    const int head = (int)(a0 - a_al), ndw = (head + nrows * W3 + 3) >> 2;
+    for (int i = threadIdx.x; i < ndw; i += 256) {
+        const long off = a_al + 4L * i;
+        unsigned v;
+        if (off + 4 <= in_bytes) v = *(const unsigned*)(in + off);
+        else { v = 0; for (int e = 0; e < 4 && off + e < in_bytes; ++e) v |= (unsigned)in[off + e] << (8 * e); }
+        ((unsigned*)rows_s)[i] = v;
+    }
+    __syncthreads();
+    const int r = threadIdx.x / SV, xo4 = (threadIdx.x - r * SV) * 4;
+    if (r >= nrows) return;
+    const unsigned char* src = rows_s + head + r * W3;
+    unsigned o[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        const int xo = xo4 + px, x0 = bx[2 * xo], cnt = bx[2 * xo + 1];
+        const int* k = kx + xo * ksx;
+        const unsigned char* p = src + x0 * 3;
+        int s0 = 1 << (PBITS - 1), s1 = s0, s2 = s0;
+        for (int j = 0; j < cnt; ++j) {
+            const int c = k[j];
+            s0 += p[3 * j] * c; s1 += p[3 * j + 1] * c; s2 += p[3 * j + 2] * c;
+        }
+        const int b0 = 3 * px;
+        o[b0 >> 2] |= (unsigned)clip8(s0) << (8 * (b0 & 3));
+        o[(b0 + 1) >> 2] |= (unsigned)clip8(s1) << (8 * ((b0 + 1) & 3));
+        o[(b0 + 2) >> 2] |= (unsigned)clip8(s2) << (8 * ((b0 + 2) & 3));
+    }
+    *(uint3*)(tmp + ((row0 + r) * S + xo4) * 3) = make_uint3(o[0], o[1], o[2]);
+}
+
+// vertical pass + rescale/normalize (256-entry table per channel): tmp [N,H,image,3] -> out [N,3,image,image].
+// One thread = 4 adjacent output pixels: 12 contiguous tmp bytes per tap (three dword loads), one 16-byte (fp32) or 8-byte (bf16)
+// store per channel plane.  VEC=1 is the scalar form for image % 4 != 0.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void resize_v_norm_kernel(const char* __restrict__ plan, const unsigned char* __restrict__ tmp,
                                                             T* __restrict__ out, long total) {
     const ResizeHdr* h = (const ResizeHdr*)plan;
@@ -162,21 +207,36 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const char* __restri
     const float* lut = (const float*)(plan + h->off_lut);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int S = h->image, xo = (int)(i % S), yo = (int)((i / S) % S);
-    const long n = i / ((long)S * S);
+    const int S = h->image, SV = S / VEC, xo = (int)(i % SV) * VEC, yo = (int)((i / SV) % S);
+    const long n = i / ((long)SV * S);
     const int y0 = by[2 * yo], cnt = by[2 * yo + 1];
     const int* k = ky + yo * h->ksy;
     const unsigned char* p = tmp + ((n * h->H + y0) * S + xo) * 3;
-    int s0 = 1 << (PBITS - 1), s1 = s0, s2 = s0;
+    int acc[3 * VEC];
+#pragma unroll
+    for (int e = 0; e < 3 * VEC; ++e) acc[e] = 1 << (PBITS - 1);
     for (int j = 0; j < cnt; ++j) {
         const int c = k[j];
         const unsigned char* q = p + (long)j * S * 3;
-        s0 += q[0] * c; s1 += q[1] * c; s2 += q[2] * c;
+        if (VEC == 4) {
+            const uint3 w = *(const uint3*)q;                  // 12 bytes, 4-byte aligned (S % 4 == 0)
+            const unsigned d[3] = {w.x, w.y, w.z};
+#pragma unroll
+            for (int e = 0; e < 12; ++e) acc[e] += (int)((d[e >> 2] >> (8 * (e & 3))) & 0xffu) * c;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc[e] += q[e] * c;
+        }
     }
     const long plane = (long)S * S, o = n * 3 * plane + (long)yo * S + xo;
-    out[o] = (T)lut[clip8(s0)];
-    out[o + plane] = (T)lut[256 + clip8(s1)];
-    out[o + 2 * plane] = (T)lut[512 + clip8(s2)];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float v[VEC];
+#pragma unroll
+        for (int px = 0; px < VEC; ++px) v[px] = lut[ch * 256 + clip8(acc[3 * px + ch])];
+        if constexpr (VEC == 4) store_f<4>(out + o + ch * plane, v);
+        else out[o + ch * plane] = (T)v[0];
+    }
 }
 
 // ---- host: Pillow's coefficient recipe (Resample.c precompute_coeffs + normalize_coeffs_8bpc), bicubic a = -0.5, support 2
@@ -348,12 +408,26 @@ extern "C" int avllm_clip_preproc(const void* plan, const uint8_t* frames, int32
                      it->second[0], it->second[1], it->second[2], H, W, image);
     }
     unsigned char* tmp = (unsigned char*)ws;
-    const long t1 = (long)N * H * image;
-    hipLaunchKernelGGL(resize_h_kernel, dim3(av_cdiv(t1, 256)), dim3(256), 0, st, (const char*)plan, frames, tmp, t1);
+    const long rows_total = (long)N * H;
+    const int rpb = image % 4 == 0 && image <= 1024 ? 256 / (image / 4) : 0;
+    if (rpb > 0 && (size_t)rpb * W * 3 + 8 <= 60 * 1024) {
+        const size_t lds = ((size_t)rpb * W * 3 + 8 + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(resize_h4_kernel, dim3(av_cdiv(rows_total, rpb)), dim3(256), lds, st, (const char*)plan, frames, tmp, rows_total,
+                           rows_total * W * 3, rpb);
+    } else {
+        const long t1 = rows_total * image;
+        hipLaunchKernelGGL(resize_h_kernel, dim3(av_cdiv(t1, 256)), dim3(256), 0, st, (const char*)plan, frames, tmp, t1);
+    }
     AV_LAUNCH_CHECK();
-    const long t2 = (long)N * image * image;
-    if (dtype == AV_F32) hipLaunchKernelGGL((resize_v_norm_kernel<float>), dim3(av_cdiv(t2, 256)), dim3(256), 0, st, (const char*)plan, tmp, (float*)out, t2);
-    else hipLaunchKernelGGL((resize_v_norm_kernel<bf16>), dim3(av_cdiv(t2, 256)), dim3(256), 0, st, (const char*)plan, tmp, (bf16*)out, t2);
+    if (image % 4 == 0) {
+        const long t2 = (long)N * image * (image / 4);
+        if (dtype == AV_F32) hipLaunchKernelGGL((resize_v_norm_kernel<float, 4>), dim3(av_cdiv(t2, 256)), dim3(256), 0, st, (const char*)plan, tmp, (float*)out, t2);
+        else hipLaunchKernelGGL((resize_v_norm_kernel<bf16, 4>), dim3(av_cdiv(t2, 256)), dim3(256), 0, st, (const char*)plan, tmp, (bf16*)out, t2);
+    } else {
+        const long t2 = (long)N * image * image;
+        if (dtype == AV_F32) hipLaunchKernelGGL((resize_v_norm_kernel<float, 1>), dim3(av_cdiv(t2, 256)), dim3(256), 0, st, (const char*)plan, tmp, (float*)out, t2);
+        else hipLaunchKernelGGL((resize_v_norm_kernel<bf16, 1>), dim3(av_cdiv(t2, 256)), dim3(256), 0, st, (const char*)plan, tmp, (bf16*)out, t2);
+    }
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

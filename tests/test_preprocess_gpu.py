@@ -43,7 +43,7 @@ def test_log_mel_silence_and_single_row(dev):
     assert np.abs(lm(torch.from_numpy(w)).cpu().numpy()[0] - P.log_mel(w)).max() < 2e-6
 
 
-@pytest.mark.parametrize("seed,h,w", FRAMES + [(7, 8, 8), (8, 50, 1000), (9, 1000, 50), (10, 223, 640)])
+@pytest.mark.parametrize("seed,h,w", FRAMES + [(7, 8, 8), (8, 50, 1000), (9, 1000, 50), (10, 223, 640), (11, 16, 5200)])
 def test_clip_frames_bit_exact(dev, seed, h, w):
     from avllm.preprocess import ClipFrames
     fr = np.stack([frame_case(seed, h, w), frame_case(seed + 100, h, w), 255 - frame_case(seed, h, w)])
