@@ -11,6 +11,10 @@ The arithmetic itself lives in third-party code that is NOT under /root/referenc
   * Pillow (unpinned; 12.2.0 in this image): Image.resize(..., BICUBIC) = src/libImaging/Resample.c (precompute_coeffs,
     normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc): 8-bit fixed point, PRECISION_BITS = 22,
     horizontal pass first with a uint8 intermediate.
+WhisperFeatureExtractor has two implementations of the same features: the float64 numpy one restated here (bit-identical, see
+make_golden_preproc.py) and, when torch is importable -- as in the reference's environment -- a float32 torch.stft one
+(:135-168) that HF documents as agreeing to 1e-5; the fixture holds both, measured spread 2e-6 .. 1.4e-5 (1.4e-4 after the
+dataset's layer norm).  The Pillow resize is integer arithmetic and is restated bit-exactly.
 Pinned by tests/golden/g6_preprocess.npz, generated here by oracle/make_golden_preproc.py from those libraries themselves."""
 import math
 
