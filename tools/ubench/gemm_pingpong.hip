@@ -432,6 +432,275 @@ __global__ __launch_bounds__(256, 1) void g4s(const bf16* __restrict__ A, const 
         }
 }
 
+// 4 waves x 128x128, 16x16x32 MFMA, BK=32 ring of 4: B fragments of the NEXT unit and the A fragments are streamed one per
+// 8-MFMA row block (72 fragment VGPRs instead of 128), everything pinned with sched_group_barrier.
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void g4t(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tiles_m = M / TM;
+    const int m0 = (blockIdx.x % tiles_m) * TM, n0 = (blockIdx.x / tiles_m) * TN;
+    const int nu = K / 32;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long sw = (long)(((lane & 3) ^ swz64(lane >> 2)) << 3);
+    const bf16* gA = A + (long)(m0 + wave * 64 + (lane >> 2)) * K + sw;
+    const bf16* gB = B + (long)(n0 + wave * 64 + (lane >> 2)) * K + sw;
+    auto stage = [&](int u) {
+        char* dst = smem + (u & 3) * 32768 + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gA + (long)q * 16 * K + (long)u * 32, dst + q * 1024);
+            glds16(gB + (long)q * 16 * K + (long)u * 32, dst + 16384 + q * 1024);
+        }
+    };
+    const int kc = ((fq ^ swz64(fr)) << 4);
+    const char* la = smem + (wr * 128 + fr) * 64 + kc;
+    const char* lb = smem + 16384 + (wc * 128 + fr) * 64 + kc;
+    bf16x8 fa[2], fb[2][8];
+    stage(0); stage(1); stage(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fb[0][j] = *(const bf16x8*)(lb + j * 1024);
+    fa[0] = *(const bf16x8*)(la);
+    auto unit = [&](int u, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        if (FLAGS & 2) {                                       // branch-free body: past the end, unit nu-1 is re-staged into a free slot
+            const int us = u + 3 < nu ? u + 3 : nu - 1;
+            char* dst = smem + ((u + 3) & 3) * 32768 + wave * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                glds16(gA + (long)q * 16 * K + (long)us * 32, dst + q * 1024);
+                glds16(gB + (long)q * 16 * K + (long)us * 32, dst + 16384 + q * 1024);
+            }
+        } else if (u + 3 < nu) stage(u + 3);
+        const int o0 = (u & 3) * 32768, o1 = ((u + 1) & 3) * 32768;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < 7) fa[(i + 1) & 1] = *(const bf16x8*)(la + o0 + (i + 1) * 1024);
+            else fa[0] = *(const bf16x8*)(la + o1);
+            fb[set ^ 1][i] = *(const bf16x8*)(lb + o1 + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[i & 1], acc[i][j], 0, 0, 0);
+            if (FLAGS & 1) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((FLAGS & 2) || u + 3 < nu) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int u = 0; u < nu; u += 2) { unit(u, IC<0>{}); unit(u + 1, IC<1>{}); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = clock64() - ck0; g_clk[1] = wall_clock64() - wk0; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16* cp = C + (long)(m0 + wr * 128 + i * 16 + fr) * N + n0 + wc * 128 + j * 16 + fq * 4;
+            const f32x4 v = acc[i][j];
+            *(bf16x4*)cp = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+}
+
+// 4 waves x 128x128 with the K loop written instruction by instruction (inline asm): accumulators pinned to AGPRs ("+a"), every
+// ds_read and MFMA in program order, counted lgkmcnt.  Row block i of a unit: read A(i+1) -> 2 MFMA -> read next unit's B(i)
+// -> 6 MFMA; the A fragment is one block ahead (128 MFMA cycles), the B fragments one whole unit ahead.
+template <int I, int SET, int FLAGS>
+__device__ __forceinline__ void g4a_block(f32x4 (&acc)[8][8], bf16x8 (&fa)[2], bf16x8 (&fb)[2][8], int la_cur, int la_nxt, int lb_nxt) {
+    if (!(FLAGS & 8)) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+    if constexpr (I < 7) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[(I + 1) & 1]) : "v"(la_cur), "n"((I + 1) * 1024));
+    else asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(la_nxt));
+#define G4A_MF(J) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fb[SET][J]), "v"(fa[I & 1]))
+    G4A_MF(0); G4A_MF(1);
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET ^ 1][I]) : "v"(lb_nxt), "n"(I * 1024));
+    G4A_MF(2); G4A_MF(3); G4A_MF(4); G4A_MF(5); G4A_MF(6); G4A_MF(7);
+#undef G4A_MF
+}
+
+// FLAGS: 1 one global->LDS load per row block instead of 8 at the top of the unit; ablations: 2 no loads, 4 no barrier, 8 no lgkmcnt,
+// 16 (with 1) the loads go to a scratch VGPR instead of LDS (same global traffic, no LDS-DMA writes); 32 (with 17) each landed
+// register is then stored with ds_write_b128 before it is reloaded (timing model of register-staged loads; results are wrong)
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void g4a(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tiles_m = M / TM;
+    const int m0 = (blockIdx.x % tiles_m) * TM, n0 = (blockIdx.x / tiles_m) * TN;
+    const int nu = K / 32;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long sw = (long)(((lane & 3) ^ swz64(lane >> 2)) << 3);
+    const bf16* gA = A + (long)(m0 + wave * 64 + (lane >> 2)) * K + sw;
+    const bf16* gB = B + (long)(n0 + wave * 64 + (lane >> 2)) * K + sw;
+    auto stage = [&](int u, int slot) {
+        char* dst = smem + slot * 32768 + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gA + (long)q * 16 * K + (long)u * 32, dst + q * 1024);
+            glds16(gB + (long)q * 16 * K + (long)u * 32, dst + 16384 + q * 1024);
+        }
+    };
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int kc = ((fq ^ swz64(fr)) << 4);
+    const int la = lds0 + (wr * 128 + fr) * 64 + kc, lb = lds0 + 16384 + (wc * 128 + fr) * 64 + kc;
+    bf16x8 fa[2], fb[2][8];
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0][0]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[0][1]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fb[0][2]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(fb[0][3]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[0][4]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(fb[0][5]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(fb[0][6]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(fb[0][7]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(la));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int lw = lds0 + wave * 4096 + lane * 16;              // FLAGS 32: where this lane's staged 16 bytes go (lane-linear, as the DMA writes)
+    f32x4 junk[8];                                              // FLAGS 16: landing registers, live ("+v") until the final vmcnt(0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) junk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto unit = [&](int u, auto setc) {
+        constexpr int SET = decltype(setc)::value;
+        const int us = u + 3 < nu ? u + 3 : nu - 1;             // past the end: unit nu-1 re-staged into a slot nobody reads
+        if (!(FLAGS & 3)) stage(us, (u + 3) & 3);
+        const bf16* sA = gA + (long)us * 32; const bf16* sB = gB + (long)us * 32;
+        char* dst = smem + ((u + 3) & 3) * 32768 + wave * 4096;
+        const int la_cur = la + (u & 3) * 32768, la_nxt = la + ((u + 1) & 3) * 32768, lb_nxt = lb + ((u + 1) & 3) * 32768;
+#define G4A_BLK(I) do { if ((FLAGS & 19) == 1) { if ((I) < 4) glds16(sA + (long)(I) * 16 * K, dst + (I) * 1024); else glds16(sB + (long)((I) - 4) * 16 * K, dst + 16384 + ((I) - 4) * 1024); } \
+                        if ((FLAGS & 19) == 17) { const bf16* gp = (I) < 4 ? sA + (long)(I) * 16 * K : sB + (long)((I) - 4) * 16 * K; \
+                                                  if (FLAGS & 32) { asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); \
+                                                      asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(lw + ((u + 3) & 3) * 32768), "v"(junk[I]), "n"(((I) & 3) * 1024 + ((I) >> 2) * 16384)); } \
+                                                  asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(junk[I]) : "v"(gp)); } \
+                        g4a_block<I, SET, FLAGS>(acc, fa, fb, la_cur, la_nxt, lb_nxt); } while (0)
+        G4A_BLK(0); G4A_BLK(1); G4A_BLK(2); G4A_BLK(3); G4A_BLK(4); G4A_BLK(5); G4A_BLK(6); G4A_BLK(7);
+#undef G4A_BLK
+        if (FLAGS & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        if (!(FLAGS & 4)) __builtin_amdgcn_s_barrier();
+    };
+    for (int u = 0; u < nu; u += 2) { unit(u, IC<0>{}); unit(u + 1, IC<1>{}); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FLAGS & 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(junk[i]));
+    }
+    if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = clock64() - ck0; g_clk[1] = wall_clock64() - wk0; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16* cp = C + (long)(m0 + wr * 128 + i * 16 + fr) * N + n0 + wc * 128 + j * 16 + fq * 4;
+            const f32x4 v = acc[i][j];
+            *(bf16x4*)cp = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+}
+
+// g4a with a ring of RING slots (RING-2 units in flight across every barrier) and the A fragment two row blocks ahead (4 buffers).
+template <int I, int SET>
+__device__ __forceinline__ void g4b_block(f32x4 (&acc)[8][8], bf16x8 (&fa)[4], bf16x8 (&fb)[2][8], int la_cur, int la_nxt, int lb_nxt) {
+    asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    if constexpr (I < 6) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[(I + 2) & 3]) : "v"(la_cur), "n"((I + 2) * 1024));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[(I + 2) & 3]) : "v"(la_nxt), "n"((I - 6) * 1024));
+#define G4B_MF(J) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fb[SET][J]), "v"(fa[I & 3]))
+    G4B_MF(0); G4B_MF(1);
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET ^ 1][I]) : "v"(lb_nxt), "n"(I * 1024));
+    G4B_MF(2); G4B_MF(3); G4B_MF(4); G4B_MF(5); G4B_MF(6); G4B_MF(7);
+#undef G4B_MF
+}
+
+template <int RING>
+__global__ __launch_bounds__(256, 1) void g4b(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tiles_m = M / TM;
+    const int m0 = (blockIdx.x % tiles_m) * TM, n0 = (blockIdx.x / tiles_m) * TN;
+    const int nu = K / 32;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long sw = (long)(((lane & 3) ^ swz64(lane >> 2)) << 3);
+    const bf16* gA = A + (long)(m0 + wave * 64 + (lane >> 2)) * K + sw;
+    const bf16* gB = B + (long)(n0 + wave * 64 + (lane >> 2)) * K + sw;
+    auto stage = [&](int u, int slot) {
+        char* dst = smem + slot * 32768 + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(gA + (long)q * 16 * K + (long)u * 32, dst + q * 1024);
+            glds16(gB + (long)q * 16 * K + (long)u * 32, dst + 16384 + q * 1024);
+        }
+    };
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int kc = ((fq ^ swz64(fr)) << 4);
+    const int la = lds0 + (wr * 128 + fr) * 64 + kc, lb = lds0 + 16384 + (wc * 128 + fr) * 64 + kc;
+    bf16x8 fa[4], fb[2][8];
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) stage(u, u);
+    if (RING == 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0][0]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[0][1]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fb[0][2]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(fb[0][3]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[0][4]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(fb[0][5]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(fb[0][6]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(fb[0][7]) : "v"(lb));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fa[1]) : "v"(la));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int s_cur = 0;                                               // slot of unit u
+    auto unit = [&](int u, auto setc) {
+        constexpr int SET = decltype(setc)::value;
+        const int us = u + RING - 1 < nu ? u + RING - 1 : nu - 1;     // past the end: unit nu-1 re-staged into a slot nobody reads
+        const int s_nxt = s_cur + 1 == RING ? 0 : s_cur + 1, s_new = s_cur == 0 ? RING - 1 : s_cur - 1;
+        const bf16* sA = gA + (long)us * 32; const bf16* sB = gB + (long)us * 32;
+        char* dst = smem + s_new * 32768 + wave * 4096;
+        const int la_cur = la + s_cur * 32768, la_nxt = la + s_nxt * 32768, lb_nxt = lb + s_nxt * 32768;
+#define G4B_BLK(I) do { if ((I) < 4) glds16(sA + (long)(I) * 16 * K, dst + (I) * 1024); else glds16(sB + (long)((I) - 4) * 16 * K, dst + 16384 + ((I) - 4) * 1024); \
+                        g4b_block<I, SET>(acc, fa, fb, la_cur, la_nxt, lb_nxt); } while (0)
+        G4B_BLK(0); G4B_BLK(1); G4B_BLK(2); G4B_BLK(3); G4B_BLK(4); G4B_BLK(5); G4B_BLK(6); G4B_BLK(7);
+#undef G4B_BLK
+        if (RING == 5) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        s_cur = s_nxt;
+    };
+    for (int u = 0; u < nu; u += 2) { unit(u, IC<0>{}); unit(u + 1, IC<1>{}); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = clock64() - ck0; g_clk[1] = wall_clock64() - wk0; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16* cp = C + (long)(m0 + wr * 128 + i * 16 + fr) * N + n0 + wc * 128 + j * 16 + fq * 4;
+            const f32x4 v = acc[i][j];
+            *(bf16x4*)cp = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+}
+
 // 16 waves, 64x64 per wave like the reference, but v_mfma_f32_32x32x16_bf16 (2x2 blocks): half the MFMA instructions and
 // operand register reads per flop.  128-B rows, chunk ^ ((row >> 1) & 7).
 __global__ __launch_bounds__(1024, 4) void g16m32(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C, int M, int N, int K) {
@@ -555,8 +824,7 @@ __global__ __launch_bounds__(1024, 4) void gref(const bf16* A, const bf16* B, bf
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-template <typename KernT> float timeit(KernT kern, int threads, const bf16* A, const bf16* B, bf16* C, int M, int N, int K, int reps) {
-    const int lds = 128 * 1024;
+template <typename KernT> float timeit(KernT kern, int threads, const bf16* A, const bf16* B, bf16* C, int M, int N, int K, int reps, int lds = 128 * 1024) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int tiles = (M / TM) * (N / TN);
@@ -615,9 +883,9 @@ after_maps:
     }
 #define RUNV(F, name) ms = timeit(gpp<F>, 512, A, B, C, M, N, K, 20); { long long hk[2]; CK(hipMemcpyFromSymbol(hk, HIP_SYMBOL(g_clk), 16)); \
     printf("%-44s %8.1f us  %8.1f TF/s   main loop %.1f us, %.0f MHz\n", name, ms * 1000, fl / ms / 1e9, hk[1] / 100.0, hk[1] ? 100.0 * hk[0] / hk[1] : 0.0); }
-    for (int v = 0; v < 7; ++v) {
+    for (int v = 0; v < 12; ++v) {
         CK(hipMemset(C, 0, (size_t)M * N * 2));
-        ms = v == 6 ? timeit(g4s<1>, 256, A, B, C, M, N, K, 20) : v == 5 ? timeit(g4s<0>, 256, A, B, C, M, N, K, 20) : v == 4 ? timeit(g16m32, 1024, A, B, C, M, N, K, 20) : v == 3 ? timeit(g4r<1>, 256, A, B, C, M, N, K, 20) : v == 2 ? timeit(g4r<0>, 256, A, B, C, M, N, K, 20) : v ? timeit(g4w<1>, 256, A, B, C, M, N, K, 20) : timeit(g4w<0>, 256, A, B, C, M, N, K, 20);
+        ms = v == 11 ? timeit(g4b<5>, 256, A, B, C, M, N, K, 20, 160 * 1024) : v == 10 ? timeit(g4b<4>, 256, A, B, C, M, N, K, 20) : v == 9 ? timeit(g4a<0>, 256, A, B, C, M, N, K, 20) : v == 8 ? timeit(g4t<1>, 256, A, B, C, M, N, K, 20) : v == 7 ? timeit(g4t<3>, 256, A, B, C, M, N, K, 20) : v == 6 ? timeit(g4s<1>, 256, A, B, C, M, N, K, 20) : v == 5 ? timeit(g4s<0>, 256, A, B, C, M, N, K, 20) : v == 4 ? timeit(g16m32, 1024, A, B, C, M, N, K, 20) : v == 3 ? timeit(g4r<1>, 256, A, B, C, M, N, K, 20) : v == 2 ? timeit(g4r<0>, 256, A, B, C, M, N, K, 20) : v ? timeit(g4w<1>, 256, A, B, C, M, N, K, 20) : timeit(g4w<0>, 256, A, B, C, M, N, K, 20);
         unsigned short* hc = (unsigned short*)malloc((size_t)M * N * 2);
         unsigned short* hr = (unsigned short*)malloc((size_t)M * N * 2);
         CK(hipMemcpy(hc, C, (size_t)M * N * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr, C2, (size_t)M * N * 2, hipMemcpyDeviceToHost));
@@ -630,9 +898,19 @@ after_maps:
             if (d > 0.02 * fabs(fy) + 0.5) ++bad;
         }
         long long hk[2]; CK(hipMemcpyFromSymbol(hk, HIP_SYMBOL(g_clk), 16));
-        printf("%-44s %8.1f us  %8.1f TF/s   max|diff| %.3f  mismatches %zu  main loop %.1f us, %.0f MHz\n", v == 6 ? "4 waves, ring, 16x16x32, pinned" : v == 5 ? "4 waves, ring, 16x16x32" : v == 4 ? "16 waves 64x64, 32x32x16 MFMA" : v == 3 ? "4 waves, ring of 4 x BK32, pinned" : v == 2 ? "4 waves, ring of 4 x BK32" : v ? "4 waves 128x128, 32x32x16, frag prefetch" : "4 waves 128x128, 32x32x16", ms * 1000, fl / ms / 1e9, maxd, bad, hk[1] / 100.0, hk[1] ? 100.0 * hk[0] / hk[1] : 0.0);
+        printf("%-44s %8.1f us  %8.1f TF/s   max|diff| %.3f  mismatches %zu  main loop %.1f us, %.0f MHz\n", v == 11 ? "asm K loop, ring 5, A two blocks ahead" : v == 10 ? "asm K loop, ring 4, A two blocks ahead" : v == 9 ? "4 waves, ring, asm K loop (AGPR acc)" : v == 8 ? "4 waves, ring, 16x16x32, streamed frags, pinned" : v == 7 ? "4 waves, ring, 16x16x32, streamed, pinned, branch-free" : v == 6 ? "4 waves, ring, 16x16x32, pinned" : v == 5 ? "4 waves, ring, 16x16x32" : v == 4 ? "16 waves 64x64, 32x32x16 MFMA" : v == 3 ? "4 waves, ring of 4 x BK32, pinned" : v == 2 ? "4 waves, ring of 4 x BK32" : v ? "4 waves 128x128, 32x32x16, frag prefetch" : "4 waves 128x128, 32x32x16", ms * 1000, fl / ms / 1e9, maxd, bad, hk[1] / 100.0, hk[1] ? 100.0 * hk[0] / hk[1] : 0.0);
         free(hc); free(hr);
     }
+#define RUNA(F, name) ms = timeit(g4a<F>, 256, A, B, C, M, N, K, 20); { long long hk[2]; CK(hipMemcpyFromSymbol(hk, HIP_SYMBOL(g_clk), 16)); \
+    printf("%-44s %8.1f us  %8.1f TF/s   main loop %.1f us, %.0f MHz\n", name, ms * 1000, fl / ms / 1e9, hk[1] / 100.0, hk[1] ? 100.0 * hk[0] / hk[1] : 0.0); }
+    RUNA(1, "asm K loop, loads spread over row blocks")
+    RUNA(2, "  ablation: no global loads in loop")
+    RUNA(1 + 4, "  ablation: no barrier (spread loads)")
+    RUNA(1 + 8, "  ablation: no lgkmcnt waits (spread loads)")
+    RUNA(2 + 4 + 8, "  ablation: mfma + ds_read issue only")
+    RUNA(1 + 16, "  ablation: loads land in VGPRs, not LDS")
+    RUNA(1 + 16 + 32, "  timing model: VGPR landing + ds_write_b128 (2 units later)")
+    if (argc > 5) return 0;
     RUNV(0, "ping-pong, no setprio")
     RUNV(1 + 2, "  no global loads in loop")
     RUNV(1 + 4, "  no ds_reads in loop")
