@@ -82,8 +82,8 @@ _SIGS = {
     "avllm_rope": ([vp, i64, i64, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "avllm_swiglu_fwd": ([vp, vp, i64, i32, i32, vp], i32),
     "avllm_swiglu_bwd": ([vp, vp, vp, i64, i32, i32, vp], i32),
-    "avllm_attention_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, i32, i32, vp], i32),
-    "avllm_attention_bwd": ([vp] * 10 + [i32] * 4 + [i64] * 7 + [f32, i32, i32, i32, vp], i32),
+    "avllm_attention_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, i32, i32, i32, vp], i32),
+    "avllm_attention_bwd": ([vp] * 10 + [i32] * 4 + [i64] * 7 + [f32, i32, i32, i32, i32, vp], i32),
     "avllm_ce_fwd": ([vp, i64, vp, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "avllm_ce_bwd": ([vp, i64, vp, vp, vp, f32, vp, i32, i32, i32, i32, vp], i32),
     "avllm_argmax_rows": ([vp, i64, i64, i32, vp, i32, vp], i32),

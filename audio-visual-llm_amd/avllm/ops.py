@@ -98,29 +98,31 @@ def swiglu_bwd(dh, gu):
     return dgu
 
 
-def attention_fwd(qkv, B, T, H, hd, causal, scale=None, impl=0, want_lse=True):
-    """qkv [B*T, 3*H*hd] fused rows -> (o [B*T, H*hd], lse [B,H,T])."""
+def attention_fwd(qkv, B, T, H, hd, causal, scale=None, impl=0, want_lse=True, kv_heads=None):
+    """qkv [B*T, (H + 2*kv_heads)*hd] fused rows [q | k | v] -> (o [B*T, H*hd], lse [B,H,T])."""
     d = H * hd
+    dkv = (kv_heads or H) * hd
     o = torch.empty(B * T, d, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32) if want_lse else None
     es = qkv.element_size()
     scale = hd ** -0.5 if scale is None else scale
     p = L.ptr(qkv)
-    L.check(L.load().avllm_attention_fwd(p, p + d * es, p + 2 * d * es, L.ptr(o), L.ptr(lse), B, T, T, H, hd, _ld(qkv), _ld(qkv),
-                                         _ld(qkv), d, scale, int(causal), L.dt_of(qkv), impl, L.stream_ptr()))
+    L.check(L.load().avllm_attention_fwd(p, p + d * es, p + (d + dkv) * es, L.ptr(o), L.ptr(lse), B, T, T, H, hd, _ld(qkv), _ld(qkv),
+                                         _ld(qkv), d, scale, int(causal), L.dt_of(qkv), impl, kv_heads or 0, L.stream_ptr()))
     return o, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B, T, H, hd, causal, scale=None, impl=0):
+def attention_bwd(qkv, o, dout, lse, B, T, H, hd, causal, scale=None, impl=0, kv_heads=None):
     d = H * hd
+    dkv = (kv_heads or H) * hd
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
     es = qkv.element_size()
     scale = hd ** -0.5 if scale is None else scale
     p, g = L.ptr(qkv), L.ptr(dqkv)
-    L.check(L.load().avllm_attention_bwd(p, p + d * es, p + 2 * d * es, L.ptr(o), L.ptr(dout), L.ptr(lse), g, g + d * es, g + 2 * d * es,
+    L.check(L.load().avllm_attention_bwd(p, p + d * es, p + (d + dkv) * es, L.ptr(o), L.ptr(dout), L.ptr(lse), g, g + d * es, g + (d + dkv) * es,
                                          L.ptr(delta), B, T, H, hd, _ld(qkv), _ld(qkv), _ld(qkv), d, _ld(dqkv), _ld(dqkv), _ld(dqkv),
-                                         scale, int(causal), L.dt_of(qkv), impl, L.stream_ptr()))
+                                         scale, int(causal), L.dt_of(qkv), impl, kv_heads or 0, L.stream_ptr()))
     return dqkv
 
 

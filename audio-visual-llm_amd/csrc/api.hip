@@ -36,14 +36,14 @@ int avllm_swiglu_fwd(const void* gu, void* h, int64_t M, int32_t F, int32_t dtyp
 int avllm_swiglu_bwd(const void* dh, const void* gu, void* dgu, int64_t M, int32_t F, int32_t dtype, void* stream) { return av_swiglu_bwd(dh, gu, dgu, M, F, dtype, ST); }
 int avllm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t Tq, int32_t Tk,
                         int32_t H, int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int32_t causal,
-                        int32_t dtype, int32_t impl, void* stream) {
-    return av_attention_fwd(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, impl, ST);
+                        int32_t dtype, int32_t impl, int32_t kv_heads, void* stream) {
+    return av_attention_fwd(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, impl, ST, kv_heads);
 }
 int avllm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
                         void* dk, void* dv, float* delta_ws, int32_t B, int32_t T, int32_t H, int32_t hd, int64_t ldq, int64_t ldk,
                         int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int32_t causal,
-                        int32_t dtype, int32_t impl, void* stream) {
-    return av_attention_bwd(q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, impl, ST);
+                        int32_t dtype, int32_t impl, int32_t kv_heads, void* stream) {
+    return av_attention_bwd(q, k, v, o, dout, lse, dq, dk, dv, delta_ws, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, impl, ST, kv_heads);
 }
 int avllm_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V, float* row_lse,
                  float* loss_sum, float* count, int32_t dtype, void* stream) { return av_ce_fwd(logits, ld, labels, B, T, V, row_lse, loss_sum, count, dtype, ST); }

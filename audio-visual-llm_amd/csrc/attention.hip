@@ -14,14 +14,14 @@
 #include "avllm_internal.h"
 
 int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
-                         int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st);
+                         int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st, int G);
 int av_attention_delta(const void* o, const void* dout, float* delta, int B, int T, int H, int hd, long ldo, long lddo, int dtype, hipStream_t st);
 int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                          void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                         long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st);
+                         long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st, int G);
 int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                           void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st);
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G);
 
 namespace {
 
@@ -33,7 +33,7 @@ template <int HD, int NW, bool CAUSAL>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                          const bf16* __restrict__ v, bf16* __restrict__ o, float* __restrict__ lse,
                                                          int Tq, int Tk, int H, long ldq, long ldk, long ldv, long ldo,
-                                                         float scale_log2e) {
+                                                         float scale_log2e, int G) {
     constexpr int KS = HD * 2 + 16;      // K tile row stride (bytes)
     constexpr int VS = HD * 2 + 64;      // V tile row stride (bytes)
     constexpr int CPR = HD / 8;          // 16-byte chunks per row
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
-    const int hh = blockIdx.y, b = blockIdx.z;
+    const int hh = blockIdx.y, b = blockIdx.z, hk = hh / G;     // hk: the key/value head this query head reads (grouped-query attention)
     const int q0 = (blockIdx.x * NW + w) * 32;
     const int off = Tk - Tq;                                   // causal: query t sees keys <= t + off
     const int qpos = q0 + r;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
             const int key = kb0 + row;
             kreg[i] = (u32x4){0u, 0u, 0u, 0u}; vreg[i] = (u32x4){0u, 0u, 0u, 0u};
             if (c < 64 * CPR && key < Tk) {
-                kreg[i] = *(const u32x4*)(k + ((long)b * Tk + key) * ldk + (long)hh * HD + ch * 8);
-                vreg[i] = *(const u32x4*)(v + ((long)b * Tk + key) * ldv + (long)hh * HD + ch * 8);
+                kreg[i] = *(const u32x4*)(k + ((long)b * Tk + key) * ldk + (long)hk * HD + ch * 8);
+                vreg[i] = *(const u32x4*)(v + ((long)b * Tk + key) * ldv + (long)hk * HD + ch * 8);
             }
         }
     };
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
             const int row = c / CPR, ch = c % CPR;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
             if (row < Tk) {
-                kv = *(const u32x4*)(k + ((long)b * Tk + row) * ldk + (long)hh * HD + ch * 8);
-                vv = *(const u32x4*)(v + ((long)b * Tk + row) * ldv + (long)hh * HD + ch * 8);
+                kv = *(const u32x4*)(k + ((long)b * Tk + row) * ldk + (long)hk * HD + ch * 8);
+                vv = *(const u32x4*)(v + ((long)b * Tk + row) * ldv + (long)hk * HD + ch * 8);
             }
             *(u32x4*)(k_lds + row * KS + ch * 16) = kv;
             *(u32x4*)(v_lds + row * VS + ch * 16) = vv;
@@ -215,11 +215,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
 
 template <int HD, int NW>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H, long ldq,
-               long ldk, long ldv, long ldo, float scale, int causal, hipStream_t st) {
+               long ldk, long ldv, long ldo, float scale, int causal, hipStream_t st, int G) {
     const dim3 grid(av_cdiv(Tq, 32 * NW), H, B), block(NW * 64);
     const float sl = scale * 1.4426950408889634f;
-    if (causal) hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl);
-    else hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl);
+    if (causal) hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl, G);
+    else hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl, G);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -228,28 +228,34 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 
 int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
                      int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, int impl,
-                     hipStream_t st) {
+                     hipStream_t st, int kv_heads) {
     AV_CHECK_ARG(q && k && v && o && B > 0 && Tq > 0 && Tk > 0 && H > 0, "attention_fwd: bad args");
+    if (kv_heads <= 0) kv_heads = H;
+    AV_CHECK_ARG(H % kv_heads == 0, "attention_fwd: %d query heads are not a multiple of %d key/value heads", H, kv_heads);
+    const int G = H / kv_heads;
     AV_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "attention_fwd: row strides must be multiples of 8");
     AV_CHECK_ARG(!causal || Tk >= Tq, "attention_fwd: causal needs Tk >= Tq");
     if (impl == 1 || dtype == AV_F32 || (hd != 64 && hd != 128))
-        return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st);
+        return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st, G);
     if (hd == 64) {
         // short sequences (CLIP: 197 tokens): one workgroup covers the whole sequence with 7 waves
-        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
-        return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
+        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
+        return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
     }
-    return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st);
+    return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
 }
 
 int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      void* dq, void* dk, void* dv, float* delta_ws, int B, int T, int H, int hd, long ldq, long ldk,
                      long ldv, long ldo, long lddq, long lddk, long lddv, float scale, int causal, int dtype, int impl,
-                     hipStream_t st) {
+                     hipStream_t st, int kv_heads) {
     AV_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta_ws, "attention_bwd: null");
+    if (kv_heads <= 0) kv_heads = H;
+    AV_CHECK_ARG(H % kv_heads == 0, "attention_bwd: %d query heads are not a multiple of %d key/value heads", H, kv_heads);
+    const int G = H / kv_heads;
     // dO shares O's row stride
     AV_TRY(av_attention_delta(o, dout, delta_ws, B, T, H, hd, ldo, ldo, dtype, st));
     if (impl == 0 && dtype == AV_BF16 && (hd == 128 || hd == 64))
-        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st);
-    return av_attention_bwd_ref(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, st);
+        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st, G);
+    return av_attention_bwd_ref(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, st, G);
 }

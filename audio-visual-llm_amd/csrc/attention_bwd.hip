@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_mfma(const bf16* __restri
                                                             const bf16* __restrict__ v, const bf16* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16* __restrict__ dq, int T, int H, long ldq, long ldk, long ldv,
-                                                            long lddo, long lddq, float scale) {
+                                                            long lddo, long lddq, float scale, int G) {
     constexpr int RS = HD * 2 + 16, TS = HD * 2 + 64, NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char k_row[64 * RS];
     __shared__ __attribute__((aligned(16))) char k_tr[64 * TS];
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_mfma(const bf16* __restri
     const int k_end = CAUSAL ? min(T, blk_qmax + 1) : T;
     const bool wave_active = q0 < T;
     const int wave_kmax = CAUSAL ? min(T - 1, q0 + 31) : T - 1;
-    const bf16* kbase = k + (long)b * T * ldk + (long)hh * HD;
-    const bf16* vbase = v + (long)b * T * ldv + (long)hh * HD;
+    const bf16* kbase = k + (long)b * T * ldk + (long)(hh / G) * HD;      // grouped-query attention: G query heads per K/V head
+    const bf16* vbase = v + (long)b * T * ldv + (long)(hh / G) * HD;
 
     RowRegs<HD, NT, 64> kr, vr;
     load_rows<HD, NT, 64>(kr, kbase, ldk, 0, T, tid);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_mfma(const bf16* __restr
                                                              const bf16* __restrict__ v, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int T, int H, long ldq,
-                                                             long ldk, long ldv, long lddo, long lddk, long lddv, float scale) {
+                                                             long ldk, long ldv, long lddo, long lddk, long lddv, float scale, int G) {
     constexpr int RS = HD * 2 + 16, TS = HD * 2 + 64, NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char q_row[32 * RS];
     __shared__ __attribute__((aligned(16))) char q_tr[32 * TS];
@@ -195,30 +195,31 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_mfma(const bf16* __restr
     const int blk_k0 = blockIdx.x * NW * 32;
     const int q_begin = CAUSAL ? (blk_k0 / 32) * 32 : 0;
     const bool wave_active = k0 < T;
-    const bf16* qbase = q + (long)b * T * ldq + (long)hh * HD;
-    const bf16* dobase = dout + (long)b * T * lddo + (long)hh * HD;
-    const float* lrow = lse + ((long)b * H + hh) * T;
-    const float* drow = delta + ((long)b * H + hh) * T;
+    // hh is the K/V head (grid.y = H / G); the G query heads of its group are walked one after the other: iteration `it` is
+    // query tile (it % ntile) of query head hh*G + it / ntile
+    const int ntile = q_begin < T ? (T - q_begin + 31) / 32 : 0, total = ntile * G;
 
     RowRegs<HD, NT, 32> qr, dr;
     float lreg = 0.f, dreg = 0.f;
-    auto fetch = [&](int qb0) {
-        load_rows<HD, NT, 32>(qr, qbase, ldq, qb0, T, tid);
-        load_rows<HD, NT, 32>(dr, dobase, lddo, qb0, T, tid);
+    auto fetch = [&](int it) {
+        const int hq = hh * G + it / ntile, qb0 = q_begin + (it % ntile) * 32;
+        load_rows<HD, NT, 32>(qr, q + (long)b * T * ldq + (long)hq * HD, ldq, qb0, T, tid);
+        load_rows<HD, NT, 32>(dr, dout + (long)b * T * lddo + (long)hq * HD, lddo, qb0, T, tid);
         if (tid < 32) {
             const int qi = qb0 + tid;
-            lreg = qi < T ? lrow[qi] * 1.4426950408889634f : 0.f;
-            dreg = qi < T ? drow[qi] : 0.f;
+            lreg = qi < T ? lse[((long)b * H + hq) * T + qi] * 1.4426950408889634f : 0.f;
+            dreg = qi < T ? delta[((long)b * H + hq) * T + qi] : 0.f;
         }
     };
-    if (q_begin < T) fetch(q_begin);
-    for (int qb = q_begin; qb < T; qb += 32) {
+    if (total > 0) fetch(0);
+    for (int it = 0; it < total; ++it) {
+        const int qb = q_begin + (it % ntile) * 32;
         __syncthreads();
         store_rows<HD, NT, 32>(qr, q_row, RS, q_tr, TS, tid);
         store_rows<HD, NT, 32>(dr, do_row, RS, do_tr, TS, tid);
         if (tid < 32) { lse_s[tid] = lreg; dlt_s[tid] = dreg; }
         __syncthreads();
-        if (qb + 32 < T) fetch(qb + 32);
+        if (it + 1 < total) fetch(it + 1);
         if (!wave_active || (CAUSAL && qb + 31 < k0)) continue;       // every query of this tile precedes the wave's keys
         f32x16 s, dp;
 #pragma unroll
@@ -276,15 +277,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_mfma(const bf16* __restr
 template <int HD>
 int launch_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, void* dq,
                void* dk, void* dv, int B, int T, int H, long ldq, long ldk, long ldv, long lddo, long lddq, long lddk, long lddv,
-               float scale, int causal, hipStream_t st) {
+               float scale, int causal, hipStream_t st, int G) {
     constexpr int NW = 4;
-    const dim3 grid(av_cdiv(T, 32 * NW), H, B), block(NW * 64);
+    const dim3 grid(av_cdiv(T, 32 * NW), H, B), gridkv(av_cdiv(T, 32 * NW), H / G, B), block(NW * 64);
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, true>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, false>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G);
     }
     AV_LAUNCH_CHECK();
     return AV_OK;
@@ -294,8 +295,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* dout, co
 
 int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                           void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st) {
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G) {
     AV_CHECK_ARG(hd == 128 || hd == 64, "attention_bwd(mfma): head_dim %d unsupported", hd);
-    if (hd == 128) return launch_bwd<128>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st);
-    return launch_bwd<64>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st);
+    if (hd == 128) return launch_bwd<128>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G);
+    return launch_bwd<64>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G);
 }

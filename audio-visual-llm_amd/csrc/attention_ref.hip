@@ -26,7 +26,7 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ qs, const T* 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                     T* __restrict__ o, float* __restrict__ lse, int Tq, int Tk, int H, int hd,
-                                                    long ldq, long ldk, long ldv, long ldo, float scale, int causal) {
+                                                    long ldq, long ldk, long ldv, long ldo, float scale, int causal, int G) {
     __shared__ float qs[4][MAXHD];
     __shared__ float ps[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, con
         const int j = kb + lane;
         const bool valid = j < Tk && j <= limit;
         float s = -INFINITY;
-        if (valid) s = scale * dot_row(qs[w], k + ((long)b * Tk + j) * ldk + (long)h * hd, hd);
+        if (valid) s = scale * dot_row(qs[w], k + ((long)b * Tk + j) * ldk + (long)(h / G) * hd, hd);
         const float mn = fmaxf(m, wave_max(s));
         const float p = valid ? __expf(s - mn) : 0.f;
         const float alpha = __expf(m - mn);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, con
         o0 *= alpha; o1 *= alpha;
         const int nj = min(64, min(Tk, limit + 1) - kb);
         for (int jj = 0; jj < nj; ++jj) {
-            const T* vr = v + ((long)b * Tk + kb + jj) * ldv + (long)h * hd;
+            const T* vr = v + ((long)b * Tk + kb + jj) * ldv + (long)(h / G) * hd;
             const float pj = ps[w][jj];
             if (lane < hd) o0 += pj * to_f(vr[lane]);
             if (lane + 64 < hd) o1 += pj * to_f(vr[lane + 64]);
@@ -86,7 +86,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_ref(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                        const T* __restrict__ dout, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, T* __restrict__ dq, int Tn, int H, int hd,
-                                                       long ldq, long ldk, long ldv, long lddo, long lddq, float scale, int causal) {
+                                                       long ldq, long ldk, long ldv, long lddo, long lddq, float scale, int causal, int G) {
     __shared__ float qs[4][MAXHD], dos[4][MAXHD];
     __shared__ float dss[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_ref(const T* __restrict__ q, 
         const bool valid = j <= limit;
         float ds = 0.f;
         if (valid) {
-            const float s = scale * dot_row(qs[w], k + ((long)b * Tn + j) * ldk + (long)h * hd, hd);
+            const float s = scale * dot_row(qs[w], k + ((long)b * Tn + j) * ldk + (long)(h / G) * hd, hd);
             const float p = __expf(s - L);
-            const float dp = dot_row(dos[w], v + ((long)b * Tn + j) * ldv + (long)h * hd, hd);
+            const float dp = dot_row(dos[w], v + ((long)b * Tn + j) * ldv + (long)(h / G) * hd, hd);
             ds = p * (dp - D) * scale;
         }
         __builtin_amdgcn_wave_barrier();
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_ref(const T* __restrict__ q, 
         __builtin_amdgcn_wave_barrier();
         const int nj = min(64, limit + 1 - kb);
         for (int jj = 0; jj < nj; ++jj) {
-            const T* kr = k + ((long)b * Tn + kb + jj) * ldk + (long)h * hd;
+            const T* kr = k + ((long)b * Tn + kb + jj) * ldk + (long)(h / G) * hd;
             const float d = dss[w][jj];
             if (lane < hd) g0 += d * to_f(kr[lane]);
             if (lane + 64 < hd) g1 += d * to_f(kr[lane + 64]);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_ref(const T* __restrict__ q,
                                                         const T* __restrict__ dout, const float* __restrict__ lse,
                                                         const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv, int Tn,
                                                         int H, int hd, long ldq, long ldk, long ldv, long lddo, long lddk, long lddv,
-                                                        float scale, int causal) {
+                                                        float scale, int causal, int G) {
     __shared__ float ks[4][MAXHD], vs[4][MAXHD];
     __shared__ float ps[4][64], dss[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -143,27 +143,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_ref(const T* __restrict__ q,
     __builtin_amdgcn_wave_barrier();
     const int first = causal ? j : 0;
     float gk0 = 0.f, gk1 = 0.f, gv0 = 0.f, gv1 = 0.f;
+    for (int g = 0; g < G; ++g) {                          // h is the K/V head; its G query heads all contribute
+    const int hq = h * G + g;
     for (int qb = (first / 64) * 64; qb < Tn; qb += 64) {
         const int i = qb + lane;
         const bool valid = i < Tn && i >= first;
         float p = 0.f, ds = 0.f;
         if (valid) {
-            const float s = scale * dot_row(ks[w], q + ((long)b * Tn + i) * ldq + (long)h * hd, hd);
-            p = __expf(s - lse[((long)b * H + h) * Tn + i]);
-            const float dp = dot_row(vs[w], dout + ((long)b * Tn + i) * lddo + (long)h * hd, hd);
-            ds = p * (dp - delta[((long)b * H + h) * Tn + i]) * scale;
+            const float s = scale * dot_row(ks[w], q + ((long)b * Tn + i) * ldq + (long)hq * hd, hd);
+            p = __expf(s - lse[((long)b * H + hq) * Tn + i]);
+            const float dp = dot_row(vs[w], dout + ((long)b * Tn + i) * lddo + (long)hq * hd, hd);
+            ds = p * (dp - delta[((long)b * H + hq) * Tn + i]) * scale;
         }
         __builtin_amdgcn_wave_barrier();
         ps[w][lane] = p; dss[w][lane] = ds;
         __builtin_amdgcn_wave_barrier();
         const int ni = min(64, Tn - qb);
         for (int ii = 0; ii < ni; ++ii) {
-            const T* qr = q + ((long)b * Tn + qb + ii) * ldq + (long)h * hd;
-            const T* dr = dout + ((long)b * Tn + qb + ii) * lddo + (long)h * hd;
+            const T* qr = q + ((long)b * Tn + qb + ii) * ldq + (long)hq * hd;
+            const T* dr = dout + ((long)b * Tn + qb + ii) * lddo + (long)hq * hd;
             const float pp = ps[w][ii], dd = dss[w][ii];
             if (lane < hd) { gv0 += pp * to_f(dr[lane]); gk0 += dd * to_f(qr[lane]); }
             if (lane + 64 < hd) { gv1 += pp * to_f(dr[lane + 64]); gk1 += dd * to_f(qr[lane + 64]); }
         }
+    }
     }
     T* ok = dk + ((long)b * Tn + j) * lddk + (long)h * hd;
     T* ov = dv + ((long)b * Tn + j) * lddv + (long)h * hd;
@@ -176,17 +179,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_ref(const T* __restrict__ q,
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, T* __restrict__ o, long ldo, int H, int hd, int Tk,
-                                                          int Tmax, float scale) {
+                                                          int Tmax, float scale, int GQ) {
     extern __shared__ float sh[];            // [Tk] scores | 8 reduction | [4][hd] partial outputs
     float* sc = sh; float* red = sc + Tk; float* part = red + 8;
-    const int h = blockIdx.x, b = blockIdx.y, d = H * hd;
+    const int h = blockIdx.x, b = blockIdx.y, d = (H / GQ) * hd;      // cache rows hold the H/GQ key/value heads
     const int G = hd >> 3;                   // lanes per row (16 for hd=128, 8 for hd=64)
     const int rows_per_pass = 256 / G;
     const int tid = threadIdx.x, dc = tid % G, rsub = tid / G;
     float qv[8];
     load_f<8>(q + (long)b * ldq + (long)h * hd + dc * 8, qv);
-    const T* kbase = kc + ((long)b * Tmax) * d + (long)h * hd + dc * 8;
-    const T* vbase = vc + ((long)b * Tmax) * d + (long)h * hd + dc * 8;
+    const T* kbase = kc + ((long)b * Tmax) * d + (long)(h / GQ) * hd + dc * 8;
+    const T* vbase = vc + ((long)b * Tmax) * d + (long)(h / GQ) * hd + dc * 8;
     float mx = -INFINITY;
     for (int t0 = 0; t0 < Tk; t0 += rows_per_pass) {
         const int t = t0 + rsub;
@@ -235,11 +238,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 }  // namespace
 
 int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
-                         int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st) {
+                         int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st, int G) {
     AV_CHECK_ARG(hd % 8 == 0 && hd <= MAXHD, "attention(ref): head_dim %d unsupported", hd);
     const dim3 grid(av_cdiv(Tq, 4), H, B);
-    if (dtype == AV_F32) hipLaunchKernelGGL((attn_fwd_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal);
-    else hipLaunchKernelGGL((attn_fwd_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal);
+    if (dtype == AV_F32) hipLaunchKernelGGL((attn_fwd_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, G);
+    else hipLaunchKernelGGL((attn_fwd_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, G);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -254,29 +257,29 @@ int av_attention_delta(const void* o, const void* dout, float* delta, int B, int
 
 int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                          void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                         long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st) {
+                         long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st, int G) {
     AV_CHECK_ARG(hd % 8 == 0 && hd <= MAXHD, "attention_bwd(ref): head_dim %d unsupported", hd);
-    const dim3 grid(av_cdiv(T, 4), H, B);
+    const dim3 grid(av_cdiv(T, 4), H, B), gridkv(av_cdiv(T, 4), H / G, B);
     if (dtype == AV_F32) {
-        hipLaunchKernelGGL((attn_bwd_dq_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, delta, (float*)dq, T, H, hd, ldq, ldk, ldv, lddo, lddq, scale, causal);
-        hipLaunchKernelGGL((attn_bwd_dkv_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, delta, (float*)dk, (float*)dv, T, H, hd, ldq, ldk, ldv, lddo, lddk, lddv, scale, causal);
+        hipLaunchKernelGGL((attn_bwd_dq_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, delta, (float*)dq, T, H, hd, ldq, ldk, ldv, lddo, lddq, scale, causal, G);
+        hipLaunchKernelGGL((attn_bwd_dkv_ref<float>), gridkv, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, delta, (float*)dk, (float*)dv, T, H, hd, ldq, ldk, ldv, lddo, lddk, lddv, scale, causal, G);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, hd, ldq, ldk, ldv, lddo, lddq, scale, causal);
-        hipLaunchKernelGGL((attn_bwd_dkv_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, hd, ldq, ldk, ldv, lddo, lddk, lddv, scale, causal);
+        hipLaunchKernelGGL((attn_bwd_dq_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, hd, ldq, ldk, ldv, lddo, lddq, scale, causal, G);
+        hipLaunchKernelGGL((attn_bwd_dkv_ref<bf16>), gridkv, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, hd, ldq, ldk, ldv, lddo, lddk, lddv, scale, causal, G);
     }
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
 
 int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
-                        int Tk, int Tmax, float scale, int dtype, hipStream_t st) {
-    AV_CHECK_ARG(q && kc && vc && o && Tk > 0 && Tk <= Tmax, "attention_decode: bad args");
+                        int Tk, int Tmax, float scale, int dtype, hipStream_t st, int G) {
+    AV_CHECK_ARG(q && kc && vc && o && Tk > 0 && Tk <= Tmax && G > 0 && H % G == 0, "attention_decode: bad args");
     AV_CHECK_ARG((hd == 64 || hd == 128) && ldq % 8 == 0, "attention_decode: head_dim %d unsupported", hd);
     const size_t sh = (size_t)(Tk + 8 + 4 * hd) * sizeof(float);
     AV_CHECK_ARG(sh <= 64 * 1024, "attention_decode: Tk=%d too long for the LDS score buffer", Tk);
     const dim3 grid(H, B);
-    if (dtype == AV_F32) hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), sh, st, (const float*)q, ldq, (const float*)kc, (const float*)vc, (float*)o, ldo, H, hd, Tk, Tmax, scale);
-    else hipLaunchKernelGGL((attn_decode_kernel<bf16>), grid, dim3(256), sh, st, (const bf16*)q, ldq, (const bf16*)kc, (const bf16*)vc, (bf16*)o, ldo, H, hd, Tk, Tmax, scale);
+    if (dtype == AV_F32) hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), sh, st, (const float*)q, ldq, (const float*)kc, (const float*)vc, (float*)o, ldo, H, hd, Tk, Tmax, scale, G);
+    else hipLaunchKernelGGL((attn_decode_kernel<bf16>), grid, dim3(256), sh, st, (const bf16*)q, ldq, (const bf16*)kc, (const bf16*)vc, (bf16*)o, ldo, H, hd, Tk, Tmax, scale, G);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

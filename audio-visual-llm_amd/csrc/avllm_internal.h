@@ -15,11 +15,11 @@ int av_swiglu_fwd(const void* gu, void* h, long M, int F, int dtype, hipStream_t
 int av_swiglu_bwd(const void* dh, const void* gu, void* dgu, long M, int F, int dtype, hipStream_t st);
 int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
                      int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, int impl,
-                     hipStream_t st);
+                     hipStream_t st, int kv_heads = 0);
 int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      void* dq, void* dk, void* dv, float* delta_ws, int B, int T, int H, int hd, long ldq, long ldk,
                      long ldv, long ldo, long lddq, long lddk, long lddv, float scale, int causal, int dtype, int impl,
-                     hipStream_t st);
+                     hipStream_t st, int kv_heads = 0);
 int av_ce_fwd(const void* logits, long ld, const int64_t* labels, int B, int T, int V, float* row_lse, float* loss_sum,
               float* count, int dtype, hipStream_t st);
 int av_ce_bwd(const void* logits, long ld, const int64_t* labels, const float* row_lse, const float* count,
@@ -41,7 +41,7 @@ int av_lora_pack(const float* A, const float* Bm, int r, int din, int dout, void
 int av_kv_append(const void* k, const void* v, long ld, void* kc, void* vc, int B, int T, int pos0, int Tmax, int d,
                  int dtype, hipStream_t st);
 int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
-                        int Tk, int Tmax, float scale, int dtype, hipStream_t st);
+                        int Tk, int Tmax, float scale, int dtype, hipStream_t st, int G = 1);
 int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st);
 int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);
 int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st);

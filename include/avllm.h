@@ -84,15 +84,17 @@ int avllm_swiglu_fwd(const void* gu, void* h, int64_t M, int32_t F, int32_t dtyp
 int avllm_swiglu_bwd(const void* dh, const void* gu, void* dgu, int64_t M, int32_t F, int32_t dtype, void* stream);
 /* softmax(QK^T*scale [+causal]) V.  q/k/v/o: row = token (b*T+t), head h at column h*hd; row strides in elements.
  * lse [B,H,Tq] (natural log) optional.  impl 0 = MFMA flash kernel (bf16 only), 1 = reference-grade scalar kernel.
+ * kv_heads (0 = H): grouped-query attention, k/v (and dk/dv) hold kv_heads heads and query head h reads head h/(H/kv_heads)
+ * (HF repeat_kv, models/llama/modeling_llama.py:203-212).
  * HF eager_attention_forward: whisper :215-238, clip :259-277, llama sdpa path. */
 int avllm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t Tq,
                         int32_t Tk, int32_t H, int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                        float scale, int32_t causal, int32_t dtype, int32_t impl, void* stream);
+                        float scale, int32_t causal, int32_t dtype, int32_t impl, int32_t kv_heads, void* stream);
 int avllm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                         const float* lse, void* dq, void* dk, void* dv, float* delta_ws, int32_t B, int32_t T,
                         int32_t H, int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq,
                         int64_t lddk, int64_t lddv, float scale, int32_t causal, int32_t dtype, int32_t impl,
-                        void* stream);
+                        int32_t kv_heads, void* stream);
 /* shifted causal-LM cross entropy (HF:loss/loss_utils.py:49-71): row (b,t) is scored against labels[b,t+1],
  * ignore_index -100 and the last position.  loss_sum/count are ACCUMULATED (zero them first). row_lse [B*T]. */
 int avllm_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V,

@@ -90,6 +90,32 @@ def test_attention_full_size(dev):
             close(dqkv, x.grad, 8e-2, 5e-2, "attention bwd full size")
 
 
+@pytest.mark.parametrize("dtype,impl", [(torch.bfloat16, 0), (torch.float32, 1)])
+@pytest.mark.parametrize("B,T,H,Hkv,hd", [(2, 200, 8, 2, 128), (1, 77, 4, 1, 64), (2, 256, 32, 8, 128)])
+def test_attention_grouped_query(dev, dtype, impl, B, T, H, Hkv, hd):
+    """Grouped-query attention (HF repeat_kv, models/llama/modeling_llama.py:203-212): K/V hold Hkv heads, query head h reads
+    head h // (H/Hkv); dK/dV sum over the group.  Checked against torch SDPA on the repeated K/V, forward and backward."""
+    import torch.nn.functional as F
+    qkv = rnd(B * T, (H + 2 * Hkv) * hd, dtype=dtype, seed=31)
+    o, lse = ops.attention_fwd(qkv, B, T, H, hd, True, impl=impl, kv_heads=Hkv)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.split([H * hd, Hkv * hd, Hkv * hd], dim=1)
+    q = q.view(B, T, H, hd).transpose(1, 2)
+    k = k.view(B, T, Hkv, hd).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    v = v.view(B, T, Hkv, hd).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(B * T, H * hd)
+    tol = (3e-2, 2e-2) if dtype == torch.bfloat16 else (2e-5, 1e-5)
+    close(o, ref.detach(), tol[0], tol[1], "gqa attention fwd")
+    dout = rnd(B * T, H * hd, dtype=dtype, seed=32)
+    ref.backward(dout.float())
+    dqkv = ops.attention_bwd(qkv, o, dout, lse, B, T, H, hd, True, impl=impl, kv_heads=Hkv)
+    err = (dqkv.float() - x.grad).pow(2).sum().sqrt() / x.grad.pow(2).sum().sqrt()
+    assert err < (2e-2 if dtype == torch.bfloat16 else 1e-5), err
+    for name, sl in (("dq", slice(0, H * hd)), ("dk", slice(H * hd, (H + Hkv) * hd)), ("dv", slice((H + Hkv) * hd, None))):
+        e = (dqkv[:, sl].float() - x.grad[:, sl]).pow(2).sum().sqrt() / x.grad[:, sl].pow(2).sum().sqrt()
+        assert e < (3e-2 if dtype == torch.bfloat16 else 1e-5), (name, e)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 5, 6])
 def test_every_gemm_tiling_agrees(dev, variant):
     """All bf16 tilings compiled into the library (A/B variants included) compute the same epilogue-fused GEMM."""
