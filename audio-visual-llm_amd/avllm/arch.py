@@ -49,6 +49,7 @@ class LlamaCfg:
     vocab: int = 32000
     eps: float = 1e-5
     theta: float = 10000.0
+    kv_heads: int = 0           # grouped-query attention: key/value heads (0 = heads)
 
     @property
     def head_dim(self):
@@ -196,11 +197,15 @@ def _cfg_from_hf_dir(path, kind):
         v = c.get("vision_config", c)
         return ClipCfg(v["hidden_size"], v["num_attention_heads"], v["num_hidden_layers"], v["intermediate_size"],
                        v.get("image_size", 224), v["patch_size"], v.get("layer_norm_eps", 1e-5))
-    if c.get("num_key_value_heads", c["num_attention_heads"]) != c["num_attention_heads"]:
-        raise NotImplementedError("grouped-query attention (num_key_value_heads != num_attention_heads) is a 'next' row (SURVEY.md §8f N3)")
+    scaling = c.get("rope_scaling") or (c.get("rope_parameters") or {})
+    if scaling.get("rope_type", scaling.get("type", "default")) not in ("default", None):
+        raise NotImplementedError(f"rope scaling '{scaling.get('rope_type', scaling.get('type'))}' (Llama-3.1 style) is not implemented: plain RoPE only")
+    if c.get("head_dim") not in (None, c["hidden_size"] // c["num_attention_heads"]):
+        raise NotImplementedError("head_dim != hidden_size / num_attention_heads is not implemented")
     rope = c.get("rope_theta", (c.get("rope_parameters") or {}).get("rope_theta", 10000.0))
+    kvh = c.get("num_key_value_heads", c["num_attention_heads"])
     return LlamaCfg(c["hidden_size"], c["num_attention_heads"], c["num_hidden_layers"], c["intermediate_size"], c["vocab_size"],
-                    c.get("rms_norm_eps", 1e-5), rope)
+                    c.get("rms_norm_eps", 1e-5), rope, 0 if kvh == c["num_attention_heads"] else kvh)
 
 
 def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lora_r, lora_alpha, use_lora, p_llm, p_whisper,

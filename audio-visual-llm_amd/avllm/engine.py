@@ -162,7 +162,7 @@ class LlamaEngine:
     """Llama + LoRA: avllm_llama_lora_fwd_loss / _bwd (training) and prefill / decode_step (generation).
 
     Trainable state: one flat fp32 buffer `lora_p` holding, per layer, [A_q,B_q,A_k,B_k,A_v,B_v,A_o,B_o]
-    (A [r,d], B [d,r]) so a layer's gradient bucket is one contiguous slice of `lora_g` for the DDP all-reduce.
+    (A [r,d], B [dout,r]; dout = d, or kv_heads*head_dim for k/v under grouped-query attention) so a layer's gradient bucket is one contiguous slice of `lora_g` for the DDP all-reduce.
     """
 
     def __init__(self, sd, cfg, lora_cfg=None, lora_sd=None, dtype=torch.bfloat16, device="cuda", training=True):
@@ -175,6 +175,12 @@ class LlamaEngine:
         m = L.Llama()
         m.dtype, m.d, m.heads, m.layers, m.ffn, m.vocab, m.lora_r = (
             L.F32 if dtype == torch.float32 else L.BF16, d, cfg.heads, cfg.layers, f, cfg.vocab, r)
+        kvh = getattr(cfg, "kv_heads", 0) or cfg.heads
+        if cfg.heads % kvh:
+            raise ValueError(f"heads={cfg.heads} is not a multiple of kv_heads={kvh}")
+        m.kv_heads = kvh
+        self.dkv = kvh * (d // cfg.heads)
+        self.douts = (d, self.dkv, self.dkv, d)                  # output width of q, k, v, o (grouped-query: k/v are narrower)
         m.eps, m.theta, m.lora_scale = cfg.eps, cfg.theta, (lora_cfg.scale if self.use_lora else 0.0)
 
         def put(val):
@@ -191,7 +197,7 @@ class LlamaEngine:
             m.lm_head_t = put(head.t()).data_ptr()
         self.layers = (L.LlamaLayer * cfg.layers)()
         # ---- LoRA masters / grads / padded operand images
-        self.per_layer = 8 * r * d
+        self.per_layer = sum(r * (d + do) for do in self.douts)
         n = cfg.layers * self.per_layer
         if self.use_lora:
             self.lora_p = torch.zeros(n, dtype=torch.float32, device=device)
@@ -200,8 +206,8 @@ class LlamaEngine:
             self.img_A = torch.zeros(cfg.layers, 4, P, d, dtype=dtype, device=device)
             self.img_ATqkv = torch.zeros(cfg.layers, d, 3 * P, dtype=dtype, device=device)
             self.img_ATo = torch.zeros(cfg.layers, d, P, dtype=dtype, device=device)
-            self.img_B = torch.zeros(cfg.layers, 4, d, P, dtype=dtype, device=device)
-            self.img_BT = torch.zeros(cfg.layers, 4, P, d, dtype=dtype, device=device)
+            self.img_B = [[torch.zeros(do, P, dtype=dtype, device=device) for do in self.douts] for _ in range(cfg.layers)]
+            self.img_BT = [[torch.zeros(P, do, dtype=dtype, device=device) for do in self.douts] for _ in range(cfg.layers)]
             if lora_sd is not None:
                 self.load_lora(lora_sd)
         for i in range(cfg.layers):
@@ -223,8 +229,8 @@ class LlamaEngine:
                 for j in range(4):
                     lm = ly.lora[j]
                     lm.A_pad = self.img_A[i, j].data_ptr()
-                    lm.B_pad = self.img_B[i, j].data_ptr()
-                    lm.BT_pad = self.img_BT[i, j].data_ptr()
+                    lm.B_pad = self.img_B[i][j].data_ptr()
+                    lm.BT_pad = self.img_BT[i][j].data_ptr()
                     if j < 3:
                         lm.AT_pad, lm.ld_at = self.img_ATqkv[i].data_ptr() + j * L.LORA_PAD * es, 3 * L.LORA_PAD
                     else:
@@ -242,8 +248,8 @@ class LlamaEngine:
     # flat-buffer offsets of module j (0..3 = q,k,v,o) in layer i: (A range, B range)
     def _slices(self, i, j):
         r, d = self.r, self.cfg.hidden
-        base = i * self.per_layer + j * 2 * r * d
-        return (base, base + r * d), (base + r * d, base + 2 * r * d)
+        base = i * self.per_layer + sum(r * (d + do) for do in self.douts[:j])
+        return (base, base + r * d), (base + r * d, base + r * d + self.douts[j] * r)
 
     def lora_views(self, buf=None):
         """dict key -> fp32 view into the flat buffer, keys `layers.{i}.{module}.lora_A|B` (oracle naming)."""
@@ -254,7 +260,7 @@ class LlamaEngine:
             for j, nm in enumerate(LORA_TARGETS):
                 a, b = self._slices(i, j)
                 out[f"layers.{i}.{nm}.lora_A"] = buf[a[0]:a[1]].view(r, d)
-                out[f"layers.{i}.{nm}.lora_B"] = buf[b[0]:b[1]].view(d, r)
+                out[f"layers.{i}.{nm}.lora_B"] = buf[b[0]:b[1]].view(self.douts[j], r)
         return out
 
     def load_lora(self, lora_sd):
@@ -272,7 +278,7 @@ class LlamaEngine:
             for j in range(4):
                 a, b = self._slices(i, j)
                 lm = self.layers[i].lora[j]
-                L.check(lib.avllm_lora_pack(self.lora_p[a[0]:a[1]].data_ptr(), self.lora_p[b[0]:b[1]].data_ptr(), r, d, d,
+                L.check(lib.avllm_lora_pack(self.lora_p[a[0]:a[1]].data_ptr(), self.lora_p[b[0]:b[1]].data_ptr(), r, d, self.douts[j],
                                             lm.A_pad, lm.AT_pad, lm.ld_at, lm.B_pad, lm.BT_pad, dt, st))
 
     # ------------------------------------------------------------------ training
@@ -306,7 +312,7 @@ class LlamaEngine:
 
     # ------------------------------------------------------------------ inference
     def alloc_cache(self, B, Tmax):
-        shape = (self.cfg.layers, B, Tmax, self.cfg.hidden)
+        shape = (self.cfg.layers, B, Tmax, self.dkv)
         return torch.empty(shape, dtype=self.dtype, device=self.device), torch.empty(shape, dtype=self.dtype, device=self.device)
 
     def prefill(self, x, kc, vc, all_logits=False):

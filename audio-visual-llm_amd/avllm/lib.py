@@ -55,7 +55,7 @@ class LlamaLayer(C.Structure):
 
 
 class Llama(C.Structure):
-    _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "vocab", "lora_r")] + \
+    _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "vocab", "lora_r", "kv_heads")] + \
                [(n, f32) for n in ("eps", "theta", "lora_scale", "lora_dropout")] + [("dropout_seed", C.c_uint32)] + \
                [(n, vp) for n in ("embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))]
 

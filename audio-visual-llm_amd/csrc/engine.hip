@@ -107,6 +107,11 @@ void carve_clip(const avllm_clip* c, int N, Bump& b, ClipWs& s, int& kpad) {
 }
 
 // ------------------------------------------------------------------ llama
+inline int llama_kv_heads(const avllm_llama* m);
+inline int llama_dkv(const avllm_llama* m);
+inline int llama_qw(const avllm_llama* m);
+inline int llama_off(const avllm_llama* m, int j);
+inline int llama_wid(const avllm_llama* m, int j);
 struct LlamaLayerAct {
     void *xn1, *qkv, *att, *tqkv, *to, *h1, *gu;
     float *rstd1, *rstd2, *lse;
@@ -129,7 +134,7 @@ void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs
     for (int l = 0; l < m->layers; ++l) {
         LlamaLayerAct& a = act[l];
         a.xn1 = b.take((size_t)M * d * es);
-        a.qkv = b.take((size_t)M * 3 * d * es);
+        a.qkv = b.take((size_t)M * llama_qw(m) * es);
         a.att = b.take((size_t)M * d * es);
         a.tqkv = b.take((size_t)M * 3 * AVLLM_LORA_PAD * es);
         a.to = b.take((size_t)M * AVLLM_LORA_PAD * es);
@@ -152,7 +157,7 @@ void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs
     w.dxn = b.take((size_t)M * d * es);
     w.dgu = b.take((size_t)M * 2 * f * es);
     w.dhmid = b.take((size_t)M * f * es);
-    w.dqkv = b.take((size_t)M * 3 * d * es);
+    w.dqkv = b.take((size_t)M * llama_qw(m) * es);
     w.datt = b.take((size_t)M * d * es);
     w.dtqkv = b.take((size_t)M * 3 * AVLLM_LORA_PAD * es);
     w.dto = b.take((size_t)M * AVLLM_LORA_PAD * es);
@@ -162,8 +167,15 @@ int check_llama(const avllm_llama* m) {
     AV_CHECK_ARG(m && m->layer && m->embed && m->norm_w && m->lm_head, "llama: null model fields");
     AV_CHECK_ARG(m->d % m->heads == 0 && m->d % 64 == 0 && m->ffn % 64 == 0, "llama: d=%d ffn=%d must be multiples of 64", m->d, m->ffn);
     AV_CHECK_ARG(m->layers > 0 && m->layers <= 256, "llama: layers=%d", m->layers);
+    AV_CHECK_ARG(m->kv_heads >= 0 && (m->kv_heads == 0 || m->heads % m->kv_heads == 0), "llama: heads=%d kv_heads=%d", m->heads, m->kv_heads);
     return AV_OK;
 }
+// grouped-query geometry: q is d wide, k and v are dkv = kv_heads*hd wide; the fused row is [q | k | v] = qw columns
+inline int llama_kv_heads(const avllm_llama* m) { return m->kv_heads > 0 ? m->kv_heads : m->heads; }
+inline int llama_dkv(const avllm_llama* m) { return llama_kv_heads(m) * (m->d / m->heads); }
+inline int llama_qw(const avllm_llama* m) { return m->d + 2 * llama_dkv(m); }
+inline int llama_off(const avllm_llama* m, int j) { return j == 0 ? 0 : (j == 1 ? m->d : m->d + llama_dkv(m)); }     // column (= wqkv row) of slice j
+inline int llama_wid(const avllm_llama* m, int j) { return j == 0 ? m->d : llama_dkv(m); }
 
 // y[:, slice j] = x W_j^T (+ t_j B_j^T)
 int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long ldw, int K, int N, const avllm_lora_mod& lm,
@@ -274,6 +286,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     carve_llama_train(m, B, S, b, w, resid, act);
     if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_lora_fwd_loss: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
     const int dt = m->dtype, d = m->d, f = m->ffn, H = m->heads, hd = d / H;
+    const int Hkv = llama_kv_heads(m), dkv = llama_dkv(m), qw = llama_qw(m);
     const size_t es = av_dtype_size(dt);
     const int M = B * S;
     AV_HIP(hipMemcpyAsync(resid[0], x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
@@ -289,14 +302,14 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
             const void* xl = nullptr;
             const uint32_t sj = m->dropout_seed + 4u * l + j;
             if (drop && !fuse_drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, sj, m->lora_dropout, dt, st)); xl = w.xd; }
-            AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j],
+            AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)llama_off(m, j) * d * es, d, d, llama_wid(m, j), P.lora[j],
                              (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
-                             (char*)a.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
+                             (char*)a.qkv + (size_t)llama_off(m, j) * es, qw, nullptr, 0, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
         }
-        AV_TRY(av_rope_tab(a.qkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 0, dt, st));      // q and k slices are adjacent: 2H heads
+        AV_TRY(av_rope_tab(a.qkv, qw, M, S, H + Hkv, hd, w.rope_tab, 0, dt, st));      // q and k slices are adjacent: H + Hkv heads
         const char* qkv = (const char*)a.qkv;
-        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, a.lse, B, S, S, H, hd, 3 * d, 3 * d,
-                                3 * d, d, 1.0f / sqrtf((float)hd), 1, dt, 0, st));
+        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)(d + dkv) * es, a.att, a.lse, B, S, S, H, hd, qw, qw,
+                                qw, d, 1.0f / sqrtf((float)hd), 1, dt, 0, st, Hkv));
         {
             const void* xl = nullptr;
             const uint32_t so = m->dropout_seed + 4u * l + 3;
@@ -332,6 +345,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
     carve_llama_train(m, B, S, b, w, resid, act);
     if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_lora_bwd: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
     const int dt = m->dtype, d = m->d, f = m->ffn, H = m->heads, hd = d / H, V = m->vocab;
+    const int Hkv = llama_kv_heads(m), dkv = llama_dkv(m), qw = llama_qw(m);
     const size_t es = av_dtype_size(dt);
     const int M = B * S, R = m->lora_r;
     const float sc = m->lora_scale;
@@ -377,20 +391,21 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
         // ---- attention
         const char* qkv = (const char*)a.qkv;
         char* dqkv = (char*)w.dqkv;
-        AV_TRY(av_attention_bwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, a.att, w.datt, a.lse, dqkv, dqkv + (size_t)d * es,
-                                dqkv + (size_t)2 * d * es, w.delta, B, S, H, hd, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
-                                1.0f / sqrtf((float)hd), 1, dt, 0, st));
-        AV_TRY(av_rope_tab(dqkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 1, dt, st));
+        AV_TRY(av_attention_bwd(qkv, qkv + (size_t)d * es, qkv + (size_t)(d + dkv) * es, a.att, w.datt, a.lse, dqkv, dqkv + (size_t)d * es,
+                                dqkv + (size_t)(d + dkv) * es, w.delta, B, S, H, hd, qw, qw, qw, d, qw, qw, qw,
+                                1.0f / sqrtf((float)hd), 1, dt, 0, st, Hkv));
+        AV_TRY(av_rope_tab(dqkv, qw, M, S, H + Hkv, hd, w.rope_tab, 1, dt, st));
         // ---- q,k,v projections (+LoRA)
         bool any = false, contiguous = true;
         for (int j = 0; j < 3; ++j) {
             const avllm_lora_mod& lj = P.lora[j];
             if (!lj.A_pad) { contiguous = false; continue; }
             any = true;
-            const char* dy = dqkv + (size_t)j * d * es;
+            const char* dy = dqkv + (size_t)llama_off(m, j) * es;
+            const int wj = llama_wid(m, j);
             char* dtj = (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es;
-            AV_TRY(av_gemm_tn(dy, 3 * d, d, (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD, R, M, lj.gB, R, 1.0f, dt, st));
-            avllm_gemm_desc gt = gemm_desc(dt, dy, 3 * d, lj.BT_pad, d, dtj, 3 * AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, d);
+            AV_TRY(av_gemm_tn(dy, qw, wj, (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD, R, M, lj.gB, R, 1.0f, dt, st));
+            avllm_gemm_desc gt = gemm_desc(dt, dy, qw, lj.BT_pad, wj, dtj, 3 * AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, wj);
             gt.alpha = sc;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.xn1;
@@ -402,7 +417,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
         }
         if (l > 0) {      // d(inputs_embeds) is not needed: encoders/connectors are frozen
             AV_CHECK_ARG(!any || contiguous || drop, "llama_lora_bwd: q/k/v AT_pad images must be the three 64-column slices of one [d,192] matrix");
-            g = gemm_desc(dt, w.dqkv, 3 * d, P.wqkv_t, 3 * d, w.dxn, d, M, d, 3 * d);
+            g = gemm_desc(dt, w.dqkv, qw, P.wqkv_t, qw, w.dxn, d, M, d, qw);
             if (any && !drop) { g.A2 = w.dtqkv; g.lda2 = 3 * AVLLM_LORA_PAD; g.B2 = P.lora[0].AT_pad; g.ldb2 = 3 * AVLLM_LORA_PAD; g.K2 = 3 * AVLLM_LORA_PAD; }
             AV_TRY(av_gemm(&g, st));
             if (any && drop) {
@@ -430,7 +445,7 @@ void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs
     const long M = (long)B * S;
     w.x = b.take((size_t)M * m->d * es);
     w.xn = b.take((size_t)M * m->d * es);
-    w.qkv = b.take((size_t)M * 3 * m->d * es);
+    w.qkv = b.take((size_t)M * llama_qw(m) * es);
     w.att = b.take((size_t)M * m->d * es);
     w.t = b.take((size_t)M * AVLLM_LORA_PAD * es);
     w.gu = b.take((size_t)M * 2 * m->ffn * es);
@@ -443,28 +458,29 @@ void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs
 int llama_infer_layer(const avllm_llama* m, int l, LlamaInferWs& w, int B, int S, int pos0, void* kc, void* vc, int Tmax, hipStream_t st) {
     const avllm_llama_layer& P = m->layer[l];
     const int dt = m->dtype, d = m->d, f = m->ffn, H = m->heads, hd = d / H, M = B * S;
+    const int Hkv = llama_kv_heads(m), dkv = llama_dkv(m), qw = llama_qw(m);
     const size_t es = av_dtype_size(dt);
-    char* kcl = (char*)kc + (size_t)l * B * Tmax * d * es;
-    char* vcl = (char*)vc + (size_t)l * B * Tmax * d * es;
+    char* kcl = (char*)kc + (size_t)l * B * Tmax * dkv * es;
+    char* vcl = (char*)vc + (size_t)l * B * Tmax * dkv * es;
     AV_TRY(av_rmsnorm_fwd(w.x, P.ln1_w, w.xn, nullptr, M, d, m->eps, dt, st));
     if (!P.lora[0].A_pad && !P.lora[1].A_pad && !P.lora[2].A_pad) {      // no adapters (decode.py path): one fused q|k|v projection
-        avllm_gemm_desc gq = gemm_desc(dt, w.xn, d, P.wqkv, d, w.qkv, 3 * d, M, 3 * d, d);
+        avllm_gemm_desc gq = gemm_desc(dt, w.xn, d, P.wqkv, d, w.qkv, qw, M, qw, d);
         AV_TRY(av_gemm(&gq, st));
     } else
     for (int j = 0; j < 3; ++j)
-        AV_TRY(lora_proj(m, w.xn, d, (const char*)P.wqkv + (size_t)j * d * d * es, d, d, d, P.lora[j], w.t, AVLLM_LORA_PAD,
-                         (char*)w.qkv + (size_t)j * d * es, 3 * d, nullptr, 0, M, st));
+        AV_TRY(lora_proj(m, w.xn, d, (const char*)P.wqkv + (size_t)llama_off(m, j) * d * es, d, d, llama_wid(m, j), P.lora[j], w.t, AVLLM_LORA_PAD,
+                         (char*)w.qkv + (size_t)llama_off(m, j) * es, qw, nullptr, 0, M, st));
     char* qkv = (char*)w.qkv;
     if (l == 0) AV_TRY(av_rope_table(w.rope_tab, S, hd, pos0, m->theta, st));
-    AV_TRY(av_rope_tab(qkv, 3 * d, M, S, 2 * H, hd, w.rope_tab, 0, dt, st));
-    AV_TRY(av_kv_append(qkv + (size_t)d * es, qkv + (size_t)2 * d * es, 3 * d, kcl, vcl, B, S, pos0, Tmax, d, dt, st));
+    AV_TRY(av_rope_tab(qkv, qw, M, S, H + Hkv, hd, w.rope_tab, 0, dt, st));
+    AV_TRY(av_kv_append(qkv + (size_t)d * es, qkv + (size_t)(d + dkv) * es, qw, kcl, vcl, B, S, pos0, Tmax, dkv, dt, st));
     const float scale = 1.0f / sqrtf((float)hd);
     if (S == 1) {
-        AV_TRY(av_attention_decode(qkv, 3 * d, kcl, vcl, w.att, d, B, H, hd, pos0 + 1, Tmax, scale, dt, st));
+        AV_TRY(av_attention_decode(qkv, qw, kcl, vcl, w.att, d, B, H, hd, pos0 + 1, Tmax, scale, dt, st, H / Hkv));
     } else {
         AV_CHECK_ARG(pos0 == 0, "llama prefill must start at position 0");
-        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, w.att, nullptr, B, S, S, H, hd, 3 * d, 3 * d, 3 * d,
-                                d, scale, 1, dt, 0, st));
+        AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)(d + dkv) * es, w.att, nullptr, B, S, S, H, hd, qw, qw, qw,
+                                d, scale, 1, dt, 0, st, Hkv));
     }
     AV_TRY(lora_proj(m, w.att, d, P.wo, d, d, d, P.lora[3], w.t, AVLLM_LORA_PAD, w.x, d, w.x, d, M, st));
     AV_TRY(av_rmsnorm_fwd(w.x, P.ln2_w, w.xn, nullptr, M, d, m->eps, dt, st));

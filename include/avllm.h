@@ -220,12 +220,12 @@ typedef struct avllm_lora_mod {      /* padded operand images (see avllm_lora_pa
 
 typedef struct avllm_llama_layer {
     const void *ln1_w, *ln2_w;
-    const void *wqkv;                /* [3d,d] rows [q;k;v] */
+    const void *wqkv;                /* [d+2*dkv, d] rows [q;k;v]  (dkv = kv_heads*hd; 3d without GQA) */
     const void *wo;                  /* [d,d] */
     const void *wgu;                 /* [2f,d] rows [gate;up] */
     const void *wdown;               /* [d,f] */
     /* transposed images for dX = dY.W (training only; NULL for inference): */
-    const void *wqkv_t;              /* [d,3d] */
+    const void *wqkv_t;              /* [d, d+2*dkv] */
     const void *wo_t;                /* [d,d] */
     const void *wgu_t;               /* [d,2f] */
     const void *wdown_t;             /* [f,d] */
@@ -234,6 +234,8 @@ typedef struct avllm_llama_layer {
 
 typedef struct avllm_llama {
     int32_t dtype, d, heads, layers, ffn, vocab, lora_r;
+    int32_t kv_heads;                /* grouped-query attention: key/value heads (0 = heads).  wqkv is [(heads+2*kv_heads)*hd, d],
+                                      * the k/v adapters' B is [kv_heads*hd, r], the KV cache rows are kv_heads*hd wide */
     float eps, theta, lora_scale;
     float lora_dropout;              /* applied by avllm_llama_lora_fwd_loss/_bwd only (training); 0 = off */
     uint32_t dropout_seed;           /* module j of layer l uses seed dropout_seed + 4*l + j; change it every step */

@@ -234,13 +234,16 @@ def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0, masks=None):
         q = lora_linear(h, sd[L + "self_attn.q_proj.weight"], lora, K + "q_proj", scale, masks)
         k = lora_linear(h, sd[L + "self_attn.k_proj.weight"], lora, K + "k_proj", scale, masks)
         v = lora_linear(h, sd[L + "self_attn.v_proj.weight"], lora, K + "v_proj", scale, masks)
-        sp = lambda t: t.view(B, T, H, hd).transpose(1, 2)
-        q, k, v = apply_rope(sp(q), cos, sin), apply_rope(sp(k), cos, sin), sp(v)
+        Hkv = getattr(c, "kv_heads", 0) or H                 # grouped-query attention: k/v carry Hkv heads (modeling_llama.py:203-212 repeat_kv)
+        sp = lambda t, n: t.view(B, T, n, hd).transpose(1, 2)
+        q, k, v = apply_rope(sp(q, H), cos, sin), apply_rope(sp(k, Hkv), cos, sin), sp(v, Hkv)
         if past is not None:
             if past[i] is not None:
                 k = torch.cat([past[i][0], k], dim=2)
                 v = torch.cat([past[i][1], v], dim=2)
             past[i] = (k, v)
+        if Hkv != H:
+            k, v = k.repeat_interleave(H // Hkv, dim=1), v.repeat_interleave(H // Hkv, dim=1)
         a = softmax_attention(q, k, v, hd ** -0.5, causal=True)
         x = x + lora_linear(a, sd[L + "self_attn.o_proj.weight"], lora, K + "o_proj", scale, masks)
         h = rms_norm(x, sd[L + "post_attention_layernorm.weight"], c.eps)

@@ -88,7 +88,7 @@ def build_reference_model(cw, cfg: Wt.ModelCfg, W, freeze_encoders=True):
         num_attention_heads=cc.heads, image_size=cc.image, patch_size=cc.patch, layer_norm_eps=cc.eps))
     llm = LlamaForCausalLM(LlamaConfig(
         hidden_size=lc.hidden, intermediate_size=lc.ffn, num_hidden_layers=lc.layers,
-        num_attention_heads=lc.heads, num_key_value_heads=lc.heads, vocab_size=lc.vocab,
+        num_attention_heads=lc.heads, num_key_value_heads=(lc.kv_heads or lc.heads), vocab_size=lc.vocab,
         rms_norm_eps=lc.eps, max_position_embeddings=4096, rope_theta=lc.theta,
         bos_token_id=1, eos_token_id=2, pad_token_id=None, tie_word_embeddings=False))
     res = whisper.load_state_dict(W["whisper"], strict=False)
@@ -269,6 +269,54 @@ def golden_optimizer():
     np.savez_compressed(os.path.join(OUT, "g5_optimizer.npz"), **out)
 
 
+def gqa_cfg():
+    """tiny model with a grouped-query LLM: 4 query heads, 2 key/value heads, head_dim 64 (Llama-3 / Mistral / TinyLlama layout)."""
+    cfg = Wt.tiny()
+    cfg.llama = Wt.LlamaCfg(hidden=256, heads=4, layers=2, ffn=512, vocab=256, kv_heads=2)
+    return cfg
+
+
+def golden_gqa(cw):
+    """G7: the reference's forward/backward/generate with num_key_value_heads < num_attention_heads."""
+    cfg = gqa_cfg()
+    seed = 3
+    W = Wt.all_weights(cfg, seed, lora_b_std=0.05)
+    B, Fr = 2, 5
+    audio, video, labels, _ = Wt.synthetic_batch(cfg, B, Fr, seed=77)
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.randint(3, cfg.llama.vocab, (B, 20), generator=g)
+    out = {"seed": np.int64(seed), "batch_seed": np.int64(77), "frames": np.int64(Fr), "prompt": prompt.numpy()}
+    m = build_reference_model(cw, cfg, W)
+    assert m.llm.model.layers[0].self_attn.k_proj.base.weight.shape == (128, 256)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.train()
+        res = m(audio=audio, video=video, prompt=prompt, labels=labels)
+        res["loss"].backward()
+        o_loss, o_logits, o_grads = O.train_step_grads(W, cfg, audio, video, prompt, labels)
+        check("gqa train logits", res["logits"].detach(), o_logits, 5e-4)
+        check("gqa train loss", res["loss"].detach(), o_loss, 1e-5)
+        out["train_loss"] = res["loss"].detach().numpy()
+        out["train_logits"] = res["logits"].detach().numpy()
+        for i, layer in enumerate(m.llm.model.layers):
+            for nm in cfg.lora.targets:
+                mod = getattr(layer.self_attn, nm)
+                for ab, p in (("A", mod.lora_A), ("B", mod.lora_B)):
+                    key = f"layers.{i}.{nm}.lora_{ab}"
+                    check("gqa grad " + key, p.grad, o_grads[key], 5e-5 * max(1.0, float(p.grad.abs().max())))
+                    out["grad." + key] = p.grad.numpy().copy()
+        m.eval()
+        m.max_seq_len = 256
+        cfg.max_seq_len = 256
+        with torch.no_grad():
+            ids = m.generate(audio=audio, video=video, max_new_tokens=10)
+        o_ids = O.generate(W, cfg, audio, video, None, max_new_tokens=10, eos_token_id=2)
+        print("  reference greedy ids (gqa):", ids.tolist())
+        assert ids.shape == o_ids.shape and torch.equal(ids, o_ids), (ids, o_ids)
+        out["generate_ids"] = ids.numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_tiny_gqa.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -277,6 +325,7 @@ def main():
     print("G1 glue"); golden_glue(cw)
     print("G5 optimizer"); golden_optimizer()
     print("G2 tiny end-to-end"); golden_e2e(cw)
+    print("G7 tiny grouped-query"); golden_gqa(cw)
     print("wrote", sorted(os.listdir(OUT)))
 
 

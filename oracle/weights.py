@@ -53,6 +53,7 @@ class LlamaCfg:
     vocab: int = 32000
     eps: float = 1e-5
     theta: float = 10000.0
+    kv_heads: int = 0           # grouped-query attention: key/value heads (0 = heads)
 
     @property
     def head_dim(self) -> int:
@@ -171,8 +172,10 @@ def llama_weights(c: LlamaCfg, seed: int = 0, dtype=torch.float32) -> dict:
     sd["model.embed_tokens.weight"] = _randn("llama.embed", seed, (c.vocab, d), 0.5, dtype=dtype)
     for i in range(c.layers):
         L = f"model.layers.{i}."
+        dkv = (c.kv_heads or c.heads) * c.head_dim
         for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            sd[L + f"self_attn.{nm}.weight"] = _randn("llama." + L + nm, seed, (d, d), 1.0 / math.sqrt(d), dtype=dtype)
+            rows = dkv if nm in ("k_proj", "v_proj") else d
+            sd[L + f"self_attn.{nm}.weight"] = _randn("llama." + L + nm, seed, (d, d), 1.0 / math.sqrt(d), dtype=dtype)[:rows].contiguous()
         sd[L + "mlp.gate_proj.weight"] = _randn("llama." + L + "gate", seed, (f, d), 1.0 / math.sqrt(d), dtype=dtype)
         sd[L + "mlp.up_proj.weight"] = _randn("llama." + L + "up", seed, (f, d), 1.0 / math.sqrt(d), dtype=dtype)
         sd[L + "mlp.down_proj.weight"] = _randn("llama." + L + "down", seed, (d, f), 1.0 / math.sqrt(f), dtype=dtype)
@@ -192,14 +195,16 @@ def lora_weights(c: LlamaCfg, l: LoraCfg, seed: int = 0, b_std: float = 0.0) -> 
     Keys: `layers.{i}.{module}.lora_A` [r, in], `layers.{i}.{module}.lora_B` [out, r].
     """
     d = c.hidden
+    dkv = (c.kv_heads or c.heads) * c.head_dim
     sd = {}
     for i in range(c.layers):
         for nm in l.targets:
+            rows = dkv if nm in ("k_proj", "v_proj") else d
             sd[f"layers.{i}.{nm}.lora_A"] = _randn(f"lora.{i}.{nm}.A", seed, (l.r, d), (1.0 / l.r) * 0.01)
             if b_std > 0:
-                sd[f"layers.{i}.{nm}.lora_B"] = _randn(f"lora.{i}.{nm}.B", seed, (d, l.r), b_std)
+                sd[f"layers.{i}.{nm}.lora_B"] = _randn(f"lora.{i}.{nm}.B", seed, (d, l.r), b_std)[:rows].contiguous()
             else:
-                sd[f"layers.{i}.{nm}.lora_B"] = torch.zeros(d, l.r)
+                sd[f"layers.{i}.{nm}.lora_B"] = torch.zeros(rows, l.r)
     return sd
 
 

@@ -108,3 +108,45 @@ def test_eval_forward_and_generate_single_modality(dev, setup):
     ref_t = O.generate(W, cfg, audio, None, None, max_new_tokens=4)
     assert torch.equal(toks.cpu(), ref_t)
     assert m.modality == "both"
+
+
+def test_grouped_query_llm_golden_and_oracle(dev, golden_dir):
+    """Grouped-query LLM (4 query heads, 2 key/value heads, head_dim 64): the REFERENCE's own outputs (g7) in fp32 mode,
+    bf16 sanity, greedy tokens identical, KV cache sized by the key/value heads."""
+    import numpy as np
+    from oracle.make_golden import gqa_cfg
+    g = np.load(f"{golden_dir}/g7_tiny_gqa.npz")
+    cfg = gqa_cfg()
+    W = Wt.all_weights(cfg, int(g["seed"]), lora_b_std=0.05)
+    audio, video, labels, _ = Wt.synthetic_batch(cfg, 2, int(g["frames"]), seed=int(g["batch_seed"]))
+    prompt = torch.from_numpy(g["prompt"])
+    m = make_model(cfg, W, "fp32").train()
+    out = m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    assert (out["logits"].float().cpu() - torch.from_numpy(g["train_logits"])).abs().max() < 1e-3
+    assert abs(float(out["loss"].detach()) - float(g["train_loss"])) < 1e-4
+    m.lora_param.grad = None
+    out["loss"].backward()
+    views = m.llm_engine.lora_views(m.lora_param.grad)
+    assert views["layers.0.k_proj.lora_B"].shape == (128, cfg.lora.r)
+    for k, gr in views.items():
+        ref = torch.from_numpy(g["grad." + k])
+        assert (gr.cpu() - ref).abs().max() <= 2e-4 * max(1e-3, float(ref.abs().max())) + 1e-7, (k, (gr.cpu() - ref).abs().max())
+    kc, _ = m.llm_engine.alloc_cache(2, 8)
+    assert kc.shape[-1] == 128
+    m256 = make_model(cfg, W, "fp32", max_seq_len=256).eval()
+    m256.eos_token_id = 2
+    ids = m256.generate(audio=audio.to(dev), video=video.to(dev), max_new_tokens=10)
+    assert torch.equal(ids.cpu(), torch.from_numpy(g["generate_ids"]))
+    # bf16 engine: same step within bf16 tolerances, with LoRA dropout exercised through the fused paths
+    m16 = make_model(cfg, W, "bf16").train()
+    o16 = m16(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    ref = torch.from_numpy(g["train_logits"])
+    err = (o16["logits"].float().cpu() - ref).abs()
+    assert err.max() < 6e-2 * max(1.0, float(ref.abs().max())) and err.mean() < 1e-2, (err.max(), err.mean())
+    m16.lora_param.grad = None
+    o16["loss"].backward()
+    num = den = 0.0
+    for k, gr in m16.llm_engine.lora_views(m16.lora_param.grad).items():
+        r_ = torch.from_numpy(g["grad." + k])
+        num += float(((gr.cpu() - r_) ** 2).sum()); den += float((r_ ** 2).sum())
+    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5

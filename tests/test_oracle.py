@@ -106,3 +106,24 @@ def test_wer_known_answers():
     assert O.wer("a", "") == 1.0
     assert O.wer("the cat", "The cat") == pytest.approx(0.5)      # case-sensitive
     assert O.wer("a b c", "b c a d") == pytest.approx(3 / 3)
+
+
+def test_grouped_query_golden(golden_dir):
+    """G7: the reference with num_key_value_heads=2 < num_attention_heads=4 (Llama-3 / Mistral layout)."""
+    from oracle.make_golden import gqa_cfg
+    g = np.load(f"{golden_dir}/g7_tiny_gqa.npz")
+    cfg = gqa_cfg()
+    W = Wt.all_weights(cfg, int(g["seed"]), lora_b_std=0.05)
+    assert W["llama"]["model.layers.0.self_attn.k_proj.weight"].shape == (128, 256)
+    assert W["lora"]["layers.0.v_proj.lora_B"].shape == (128, cfg.lora.r)
+    audio, video, labels, _ = Wt.synthetic_batch(cfg, 2, int(g["frames"]), seed=int(g["batch_seed"]))
+    prompt = torch.from_numpy(g["prompt"])
+    loss, logits, grads = O.train_step_grads(W, cfg, audio, video, prompt, labels)
+    assert (logits - torch.from_numpy(g["train_logits"])).abs().max() < 5e-4
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-5
+    for k, gr in grads.items():
+        ref = torch.from_numpy(g["grad." + k])
+        assert (gr - ref).abs().max() <= 5e-5 * max(1.0, float(ref.abs().max())), k
+    cfg.max_seq_len = 256
+    ids = O.generate(W, cfg, audio, video, None, max_new_tokens=10, eos_token_id=2)
+    assert torch.equal(ids, torch.from_numpy(g["generate_ids"]))
