@@ -88,6 +88,11 @@ CLIP = {
 LLAMA = {
     "llama-2-7b": LlamaCfg(4096, 32, 32, 11008, 32000, 1e-5, 10000.0),
     "llama-2-13b": LlamaCfg(5120, 40, 40, 13824, 32000, 1e-5, 10000.0),
+    # grouped-query members of the same architecture (kv_heads < heads)
+    "llama-2-70b": LlamaCfg(8192, 64, 80, 28672, 32000, 1e-5, 10000.0, 8),
+    "llama-3-8b": LlamaCfg(4096, 32, 32, 14336, 128256, 1e-5, 500000.0, 8),
+    "tinyllama": LlamaCfg(2048, 32, 22, 5632, 32000, 1e-5, 10000.0, 4),
+    "mistral-7b": LlamaCfg(4096, 32, 32, 14336, 32000, 1e-5, 10000.0, 8),     # sliding window 4096 >= every sequence of this path
 }
 
 

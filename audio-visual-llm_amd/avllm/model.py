@@ -58,6 +58,12 @@ class ClipWhisperModel:
         L.load()                                   # fail loudly when the HIP library is missing
         self.device = device
         self.use_fp16, self.use_4bit, self.use_lora = use_fp16, use_4bit, use_lora
+        if use_lora and "llama" not in str(llm_path).lower():
+            # clip_whisper_model.py:966-970 picks target modules ["query","key","value","dense"] for such paths; no Llama/Mistral
+            # module carries those names, so peft raises and the reference "continues without LoRA" (:1002-1005).  This build
+            # attaches the q/k/v/o adapters to every Llama-architecture model instead.
+            logging.warning("LLM path %r does not contain 'llama': the reference would train without LoRA here; "
+                            "this build applies LoRA to q_proj/k_proj/v_proj/o_proj", llm_path)
         self.lora_r, self.lora_alpha, self.lora_dropout = lora_r, lora_alpha, lora_dropout
         self.freeze_encoders, self.freeze_llm = freeze_encoders, freeze_llm
         self.modality, self.max_seq_len, self.fusion_scale = modality, max_seq_len, fusion_scale
