@@ -174,8 +174,9 @@ def synth_llama(c, device, dtype, seed):
           "lm_head.weight": g.n((c.vocab, d), 1 / math.sqrt(d))}
     for i in range(c.layers):
         p = f"model.layers.{i}."
+        dkv = (c.kv_heads or c.heads) * c.head_dim           # grouped-query attention: k/v project to kv_heads*head_dim
         for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            sd[p + f"self_attn.{nm}.weight"] = g.n((d, d), 1 / math.sqrt(d))
+            sd[p + f"self_attn.{nm}.weight"] = g.n((dkv if nm in ("k_proj", "v_proj") else d, d), 1 / math.sqrt(d))
         sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = g.n((f, d), 1 / math.sqrt(d)), g.n((f, d), 1 / math.sqrt(d))
         sd[p + "mlp.down_proj.weight"] = g.n((d, f), 1 / math.sqrt(f))
         sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = g.n((d,), 0.1, 1.0), g.n((d,), 0.1, 1.0)
@@ -189,7 +190,8 @@ def synth_lora(c, l, device, seed):
     for i in range(c.layers):
         for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
             sd[f"layers.{i}.{nm}.lora_A"] = g.n((l.r, c.hidden), (1.0 / l.r) * 0.01)
-            sd[f"layers.{i}.{nm}.lora_B"] = torch.zeros(c.hidden, l.r, device=device)
+            rows = (c.kv_heads or c.heads) * c.head_dim if nm in ("k_proj", "v_proj") else c.hidden
+            sd[f"layers.{i}.{nm}.lora_B"] = torch.zeros(rows, l.r, device=device)
     return sd
 
 

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
+    ap.add_argument("--llm", default="meta-llama/Llama-2-7b-hf", help="LLM architecture by name (BASELINE config = Llama-2-7B); e.g. "
+                    "meta-llama/Meta-Llama-3-8B or TinyLlama/TinyLlama-1.1B for the grouped-query family")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,9 +98,10 @@ def main():
         model = ClipWhisperModel(device=dev, max_seq_len=args.max_seq_len, config=cfg, precision=args.precision, seed=0)
         name = "tiny"
     else:
-        model = ClipWhisperModel("meta-llama/Llama-2-7b-hf", "openai/whisper-small", "openai/clip-vit-base-patch16", device=dev,
+        model = ClipWhisperModel(args.llm, "openai/whisper-small", "openai/clip-vit-base-patch16", device=dev,
                                  max_seq_len=args.max_seq_len, precision=args.precision, seed=0)
-        name = "whisper-small+clip-vit-b16->llama-2-7b lora r16"
+        name = "whisper-small+clip-vit-b16->" + ("llama-2-7b" if "llama-2-7b" in args.llm.lower() else args.llm) + " lora r16"
+    default_llm = "llama-2-7b" in args.llm.lower()
     cfg = model.cfg
     model.train()
     trainer = ClipWhisperTrainer(model, learning_rate=5e-5, weight_decay=0.01, grad_clip=0.5, total_steps=max(1000, args.steps + args.warmup))
@@ -135,11 +138,11 @@ def main():
         clips = args.batch * world * args.steps
         value = clips / dt
         out = {
-            "metric": "AV-clip train-step samples/sec (clip_whisper -> Llama-2-7B LoRA), whole job",
+            "metric": "AV-clip train-step samples/sec (clip_whisper -> " + ("Llama-2-7B" if default_llm else args.llm) + " LoRA), whole job",
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {name}, synthetic LRS3-shaped 5 s clips ({args.frames} frames), "
+            "config": {"workload": ("BASELINE configs[1]: " if default_llm and not args.tiny else "variant (not the BASELINE config): ") + f"{name}, synthetic LRS3-shaped 5 s clips ({args.frames} frames), "
                                    f"max_seq_len {args.max_seq_len}, train seq 256", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "samples_per_s_per_gpu": round(value / world, 4),
                        "final_loss": round(final_loss, 5)},
