@@ -233,8 +233,10 @@ def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lor
                     parts[kind] = ClipCfg(hc.hidden_size, hc.num_attention_heads, hc.num_hidden_layers, hc.intermediate_size,
                                           hc.image_size, hc.patch_size, hc.layer_norm_eps)
                 else:
+                    kvh = getattr(hc, "num_key_value_heads", None) or hc.num_attention_heads
+                    rope = getattr(hc, "rope_theta", None) or (getattr(hc, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
                     parts[kind] = LlamaCfg(hc.hidden_size, hc.num_attention_heads, hc.num_hidden_layers, hc.intermediate_size,
-                                           hc.vocab_size, hc.rms_norm_eps, getattr(hc, "rope_theta", 10000.0) or 10000.0)
+                                           hc.vocab_size, hc.rms_norm_eps, rope, 0 if kvh == hc.num_attention_heads else kvh)
             elif isinstance(path, str) and os.path.isdir(path) and os.path.exists(os.path.join(path, "config.json")):
                 parts[kind] = _cfg_from_hf_dir(path, kind)
             else:
@@ -257,6 +259,8 @@ def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lor
             sd = _strip(sd, "model.")
         if kind == "clip":
             sd = _strip(sd, "vision_model.")
+        if kind == "llama" and "lm_head.weight" not in sd and "model.embed_tokens.weight" in sd:
+            sd["lm_head.weight"] = sd["model.embed_tokens.weight"]          # tie_word_embeddings checkpoints store one copy
         W[kind] = sd
     if use_lora and "lora" not in W:
         W["lora"] = synth_lora(cfg.llama, cfg.lora, device, seed)
