@@ -82,11 +82,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # AVLLM_BENCH_SHARED_GPU=1: rehearsal of the multi-rank plumbing on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL);
+    # the numbers it prints are not a measurement
+    rehearsal = os.environ.get("AVLLM_BENCH_SHARED_GPU") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from avllm import lib as L
     from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
