@@ -22,7 +22,7 @@ def run():
     loss, logits, grads = O.train_step_grads(W, oc, audio, video, prompt, labels)
     dl = (out["logits"].float().cpu() - logits).abs().max().item()
     assert dl < 1e-3, f"smoke: logits differ from the oracle by {dl}"
-    assert abs(float(out["loss"]) - float(loss)) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(loss)) < 1e-4
     gv = m.llm_engine.lora_views(m.lora_param.grad)
     for k, g in grads.items():
         d = (gv[k].cpu() - g).abs().max().item()
