@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int MAXV = 8;   // vectors of 4 per thread
+constexpr int MAXV = 8;   // vectors per thread; VEC = 4 elements (fp32: 16 B, bf16: 8 B) or 8 (bf16: 16 B)
 
 template <int NT> __device__ __forceinline__ float row_sum(float v, float* red) {
     if constexpr (NT == 64) return wave_sum(v);
@@ -15,7 +15,7 @@ template <int NT> __device__ __forceinline__ float row_sum(float v, float* red) 
 }
 
 // MODE 0: layernorm (w,b)   MODE 1: rmsnorm fwd (w, writes rstd)
-template <typename T, int NT, int MODE>
+template <typename T, int NT, int MODE, int VEC>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                        const T* __restrict__ b, T* __restrict__ y,
                                                        float* __restrict__ rstd_out, long rows, int d, float eps) {
@@ -26,23 +26,29 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
     const bool active = row < rows;           // NT==256: uniform; NT==64: per wave
     if (NT == 64 && !active) return;
     const T* xr = x + (active ? row : 0) * d;
-    float v[MAXV][4];
+    float v[MAXV][VEC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * NT + t) * 4;
-        if (c < d) { load_f<4>(xr + c, v[i]); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
-        else { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+        const int c = (i * NT + t) * VEC;
+        if (c < d) {
+            load_f<VEC>(xr + c, v[i]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += v[i][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
+        }
     }
     float mean = 0.f;
     if (MODE == 0) mean = row_sum<NT>(s, red) / d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * NT + t) * 4;
+        const int c = (i * NT + t) * VEC;
         if (c < d) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float u = v[i][j] - mean; q += u * u; }
+            for (int j = 0; j < VEC; ++j) { const float u = v[i][j] - mean; q += u * u; }
         }
     }
     const float var = row_sum<NT>(q, red) / d;
@@ -52,26 +58,26 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
     T* yr = y + row * d;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * NT + t) * 4;
+        const int c = (i * NT + t) * VEC;
         if (c < d) {
-            float wv[4], o[4];
-            load_f<4>(w + c, wv);
+            float wv[VEC], o[VEC];
+            load_f<VEC>(w + c, wv);
             if (MODE == 0) {
-                float bv[4];
-                load_f<4>(b + c, bv);
+                float bv[VEC];
+                load_f<VEC>(b + c, bv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+                for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = wv[j] * (v[i][j] * rstd);
+                for (int j = 0; j < VEC; ++j) o[j] = wv[j] * (v[i][j] * rstd);
             }
-            store_f<4>(yr + c, o);
+            store_f<VEC>(yr + c, o);
         }
     }
 }
 
 // dx = dres + rstd*(w*dy) - x*rstd^3*mean(w*dy*x)
-template <typename T, int NT>
+template <typename T, int NT, int VEC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const T* __restrict__ w, const float* __restrict__ rstd,
                                                           const T* __restrict__ dres, T* __restrict__ dx, long rows, int d) {
@@ -82,18 +88,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
     const bool active = row < rows;
     if (NT == 64 && !active) return;
     const long r = active ? row : 0;
-    float xv[MAXV][4], gv[MAXV][4];
+    float xv[MAXV][VEC], gv[MAXV][VEC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * NT + t) * 4;
+        const int c = (i * NT + t) * VEC;
         if (c < d) {
-            float wv[4], dv[4];
-            load_f<4>(x + r * d + c, xv[i]);
-            load_f<4>(dy + r * d + c, dv);
-            load_f<4>(w + c, wv);
+            float wv[VEC], dv[VEC];
+            load_f<VEC>(x + r * d + c, xv[i]);
+            load_f<VEC>(dy + r * d + c, dv);
+            load_f<VEC>(w + c, wv);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { gv[i][j] = wv[j] * dv[j]; s += gv[i][j] * xv[i][j]; }
+            for (int j = 0; j < VEC; ++j) { gv[i][j] = wv[j] * dv[j]; s += gv[i][j] * xv[i][j]; }
         }
     }
     const float dot = row_sum<NT>(s, red);
@@ -102,28 +108,47 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
     const float coef = dot * rs * rs * rs / d;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * NT + t) * 4;
+        const int c = (i * NT + t) * VEC;
         if (c < d) {
-            float o[4], dr[4] = {0.f, 0.f, 0.f, 0.f};
-            if (dres) load_f<4>(dres + row * d + c, dr);
+            float o[VEC], dr[VEC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = dr[j] + rs * gv[i][j] - xv[i][j] * coef;
-            store_f<4>(dx + row * d + c, o);
+            for (int j = 0; j < VEC; ++j) dr[j] = 0.f;
+            if (dres) load_f<VEC>(dres + row * d + c, dr);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = dr[j] + rs * gv[i][j] - xv[i][j] * coef;
+            store_f<VEC>(dx + row * d + c, o);
         }
     }
 }
 
-template <typename T, int MODE>
-int launch_fwd(const void* x, const void* w, const void* b, void* y, float* rstd, long rows, int d, float eps, hipStream_t st) {
-    if (d <= 64 * 4 * MAXV) {
-        hipLaunchKernelGGL((norm_fwd_kernel<T, 64, MODE>), dim3(av_cdiv(rows, 4)), dim3(256), 0, st, (const T*)x, (const T*)w,
+template <typename T, int MODE, int VEC>
+int launch_fwd_v(const void* x, const void* w, const void* b, void* y, float* rstd, long rows, int d, float eps, hipStream_t st) {
+    if (d <= 64 * VEC * MAXV) {
+        hipLaunchKernelGGL((norm_fwd_kernel<T, 64, MODE, VEC>), dim3(av_cdiv(rows, 4)), dim3(256), 0, st, (const T*)x, (const T*)w,
                            (const T*)b, (T*)y, rstd, rows, d, eps);
     } else {
-        hipLaunchKernelGGL((norm_fwd_kernel<T, 256, MODE>), dim3(rows), dim3(256), 0, st, (const T*)x, (const T*)w,
+        hipLaunchKernelGGL((norm_fwd_kernel<T, 256, MODE, VEC>), dim3(rows), dim3(256), 0, st, (const T*)x, (const T*)w,
                            (const T*)b, (T*)y, rstd, rows, d, eps);
     }
     AV_LAUNCH_CHECK();
     return AV_OK;
+}
+// bf16 rows that fill whole waves with 16-byte vectors (d % 512 == 0, e.g. Llama's 4096: one wave per row) use them; shorter rows
+// such as 768 keep 8-byte vectors with every lane busy (measured: 16-byte vectors with 32 idle lanes are 23 % slower there)
+template <typename T, int MODE>
+int launch_fwd(const void* x, const void* w, const void* b, void* y, float* rstd, long rows, int d, float eps, hipStream_t st) {
+    if (sizeof(T) == 2 && d % 512 == 0) return launch_fwd_v<T, MODE, 8>(x, w, b, y, rstd, rows, d, eps, st);
+    return launch_fwd_v<T, MODE, 4>(x, w, b, y, rstd, rows, d, eps, st);
+}
+
+template <typename T, int VEC>
+void launch_rms_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres_in, void* dx_out, long rows, int d, hipStream_t st) {
+    if (d <= 64 * VEC * MAXV)
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, 64, VEC>), dim3(av_cdiv(rows, 4)), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)w, rstd,
+                           (const T*)dres_in, (T*)dx_out, rows, d);
+    else
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, 256, VEC>), dim3(rows), dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)w, rstd,
+                           (const T*)dres_in, (T*)dx_out, rows, d);
 }
 
 }  // namespace
@@ -146,21 +171,9 @@ int av_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rs
                    long rows, int d, int dtype, hipStream_t st) {
     AV_CHECK_ARG(dy && x && w && rstd && dx_out && rows > 0, "rmsnorm_bwd: null/empty");
     AV_CHECK_ARG(d % 4 == 0 && d <= 256 * 4 * MAXV, "rmsnorm_bwd: d=%d unsupported", d);
-    if (dtype == AV_F32) {
-        if (d <= 64 * 4 * MAXV)
-            hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, 64>), dim3(av_cdiv(rows, 4)), dim3(256), 0, st, (const float*)dy,
-                               (const float*)x, (const float*)w, rstd, (const float*)dres_in, (float*)dx_out, rows, d);
-        else
-            hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, 256>), dim3(rows), dim3(256), 0, st, (const float*)dy,
-                               (const float*)x, (const float*)w, rstd, (const float*)dres_in, (float*)dx_out, rows, d);
-    } else {
-        if (d <= 64 * 4 * MAXV)
-            hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16, 64>), dim3(av_cdiv(rows, 4)), dim3(256), 0, st, (const bf16*)dy,
-                               (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres_in, (bf16*)dx_out, rows, d);
-        else
-            hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16, 256>), dim3(rows), dim3(256), 0, st, (const bf16*)dy,
-                               (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres_in, (bf16*)dx_out, rows, d);
-    }
+    if (dtype == AV_F32) launch_rms_bwd<float, 4>(dy, x, w, rstd, dres_in, dx_out, rows, d, st);
+    else if (d % 512 == 0) launch_rms_bwd<bf16, 8>(dy, x, w, rstd, dres_in, dx_out, rows, d, st);
+    else launch_rms_bwd<bf16, 4>(dy, x, w, rstd, dres_in, dx_out, rows, d, st);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
