@@ -249,7 +249,10 @@ class ClipWhisperModel:
         if not (self.training and self.use_lora and self.lora_dropout):
             return {"dropout": 0.0, "seed": 0}
         self._drop_step += 1
-        return {"dropout": float(self.lora_dropout), "seed": (self._drop_step * 0x9E3779B1 + 12345) & 0xFFFFFFFF}
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()           # data-parallel ranks draw independent masks, as independent processes would
+        return {"dropout": float(self.lora_dropout), "seed": (self._drop_step * 0x9E3779B1 + rank * 0x85EBCA6B + 12345) & 0xFFFFFFFF}
 
     def _prep_labels(self, labels):
         if isinstance(labels, list):
