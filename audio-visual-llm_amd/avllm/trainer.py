@@ -52,6 +52,15 @@ class ClipWhisperTrainer:
 
     # ---- _process_batch :604-680
     def _unpack(self, batch):
+        if isinstance(batch, dict) and "raw" in batch:
+            # raw samples from avllm.data.AVSRDataset: log-mel / layer norm / CLIP resize+normalise happen here, on the device
+            from .preprocess import ClipFrames, WhisperLogMel, device_collate
+            if getattr(self, "_featurizers", None) is None:
+                dev = self.model.device
+                self._featurizers = (WhisperLogMel(dev), ClipFrames(dev, image=self.model.cfg.clip.image))
+            audio, video = device_collate(batch["raw"], *self._featurizers)
+            tok = self.model.tokenizer(batch["texts"], return_tensors="pt", padding=True, truncation=True, max_length=self.model.max_seq_len)
+            return audio, video, batch["labels"], tok.input_ids
         if isinstance(batch, dict):
             return batch.get("audio"), batch.get("video"), batch.get("labels"), batch.get("prompt")
         audio, video, texts, labels = batch

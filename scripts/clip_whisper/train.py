@@ -76,14 +76,22 @@ def main():
                              freeze_encoders=cfg.get("freeze_encoders", True), modality=cfg.get("modality", "both"),
                              max_seq_len=cfg.get("max_seq_len", 256), fusion_scale=cfg.get("fusion_scale", 0.5),
                              connector_type=cfg.get("connector_type", "simple"), **kw)
-    if not a.synthetic:
-        raise SystemExit("LRS3 manifests need soundfile/cv2 + processors that are not available offline; use --synthetic N "
-                         "(the dataset layer, simple_dataset.py, is a 'next' row: SURVEY.md §8f N2)")
-    frames = a.frames if not a.tiny else 5
-    ds = SyntheticClips(a.synthetic, model.cfg, frames, model.tokenizer, cfg.get("seed", 42))
-    sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=True) if world > 1 else None
-    dl = torch.utils.data.DataLoader(ds, batch_size=cfg.get("batch_size", 4), shuffle=sampler is None, sampler=sampler, collate_fn=ds.collate)
-    vdl = torch.utils.data.DataLoader(SyntheticClips(max(2, a.synthetic // 8), model.cfg, frames, model.tokenizer, 7), batch_size=cfg.get("batch_size", 4), collate_fn=ds.collate)
+    if a.synthetic:
+        frames = a.frames if not a.tiny else 5
+        ds = SyntheticClips(a.synthetic, model.cfg, frames, model.tokenizer, cfg.get("seed", 42))
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=True) if world > 1 else None
+        dl = torch.utils.data.DataLoader(ds, batch_size=cfg.get("batch_size", 4), shuffle=sampler is None, sampler=sampler, collate_fn=ds.collate)
+        vdl = torch.utils.data.DataLoader(SyntheticClips(max(2, a.synthetic // 8), model.cfg, frames, model.tokenizer, 7), batch_size=cfg.get("batch_size", 4), collate_fn=ds.collate)
+    else:
+        # LRS3-style manifests (configs/clip_whisper.yaml data.path / train_manifest / train_labels): raw samples, features on the device
+        from avllm.data import AVSRDataset, create_dataloaders
+        root = cfg.get("path") or "."
+        mp = os.path.join(root, cfg.get("train_manifest", "train.tsv")); lp = os.path.join(root, cfg.get("train_labels", "train.wrd"))
+        sampler = None
+        if world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(AVSRDataset(mp, lp, root, model.tokenizer, modality=cfg.get("modality", "both")), shuffle=True)
+        dl, vdl = create_dataloaders(mp, lp, root, model.tokenizer, batch_size=cfg.get("batch_size", 4), num_workers=cfg.get("num_workers", 0),
+                                     modality=cfg.get("modality", "both"), max_video_length=cfg.get("max_video_length", 300), sampler=sampler)
     tr = ClipWhisperTrainer(model, dl, vdl, learning_rate=float(cfg.get("learning_rate", 5e-5)), weight_decay=float(cfg.get("weight_decay", 0.01)),
                             max_epochs=cfg.get("num_epochs", 10), output_dir=cfg["output_dir"], device=f"cuda:{local}", fp16=bool(cfg.get("use_fp16")),
                             grad_accum_steps=cfg.get("grad_accum_steps", 1), log_interval=cfg.get("log_interval", 10), save_every=cfg.get("save_every", 1),

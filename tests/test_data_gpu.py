@@ -1,0 +1,39 @@
+"""Files on disk -> avllm.data.AVSRDataset -> device-side features -> trainer steps, against the oracle fed with features the
+oracle's own preprocessing made from the same files."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import avsr_oracle as O  # noqa: E402
+from oracle import preprocess as P  # noqa: E402
+from oracle import weights as Wt  # noqa: E402
+from test_data_cpu import make_set  # noqa: E402
+from test_model_gpu import make_model  # noqa: E402
+
+
+def test_training_step_from_files_matches_oracle(dev, tmp_path):
+    from avllm.data import AVSRDataset, create_dataloaders
+    from avllm.trainer import ClipWhisperTrainer
+    oc = Wt.tiny()
+    W = Wt.all_weights(oc, 21, lora_b_std=0.05)
+    m = make_model(oc, W, "fp32").train()
+    mp, lp = make_set(tmp_path, n=4)
+    dl, _ = create_dataloaders(str(mp), str(lp), str(tmp_path), m.tokenizer, batch_size=2, shuffle=False, max_video_length=4)
+    tr = ClipWhisperTrainer(m, dl, None, learning_rate=1e-3, max_epochs=1, total_steps=10, grad_clip=0.5)
+    batch = next(iter(dl))
+    audio, video, labels, prompt = tr._unpack(batch)
+    S = oc.clip.image
+    assert audio.shape == (2, 80, 3000) and video.shape == (2, 4, 3, S, S)
+    # the oracle's view of the same two files
+    ds = AVSRDataset(str(mp), str(lp), str(tmp_path), m.tokenizer, max_video_length=4)
+    ref_a = torch.from_numpy(np.stack([P.audio_features(ds[i]["wave"]) for i in range(2)]))
+    ref_v = torch.zeros(2, 4, 3, S, S)
+    for i in range(2):
+        fr = ds[i]["frames"]
+        ref_v[i, : len(fr)] = torch.from_numpy(np.stack([P.clip_pixel_values(f, S) for f in fr]))
+    assert torch.equal(video.cpu(), ref_v) and (audio.cpu() - ref_a).abs().max() < 2e-5
+    ref_loss, _, _ = O.train_step_grads(W, oc, ref_a, ref_v, prompt, labels)
+    loss = tr.train_step(audio, video, labels, prompt)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
