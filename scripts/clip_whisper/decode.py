@@ -20,6 +20,7 @@ def main():
     p.add_argument("--output_dir", default="outputs/decode"); p.add_argument("--modality", default="both")
     p.add_argument("--batch_size", type=int, default=4); p.add_argument("--max_new_tokens", type=int, default=100)
     p.add_argument("--temperature", type=float, default=1.0); p.add_argument("--load_lora", action="store_true")
+    p.add_argument("--data_path"); p.add_argument("--test_manifest"); p.add_argument("--test_labels")
     p.add_argument("--synthetic", type=int, default=0); p.add_argument("--tiny", action="store_true"); p.add_argument("--frames", type=int, default=125)
     a = p.parse_args()
     from avllm.config import merged
@@ -39,16 +40,32 @@ def main():
         sd = ck.get("model_state_dict", ck)
         keep = {k: v for k, v in sd.items() if "audio_connector" in k or "video_connector" in k or (a.load_lora and "lora_" in k)}
         model.load_state_dict(keep)
-    if not a.synthetic:
-        raise SystemExit("use --synthetic N (no LRS3 data offline)")
-    ds = SyntheticClips(a.synthetic, model.cfg, 5 if a.tiny else a.frames, model.tokenizer, 11)
-    dl = torch.utils.data.DataLoader(ds, batch_size=a.batch_size, collate_fn=ds.collate)
+    if a.synthetic:
+        ds = SyntheticClips(a.synthetic, model.cfg, 5 if a.tiny else a.frames, model.tokenizer, 11)
+        batches = torch.utils.data.DataLoader(ds, batch_size=a.batch_size, collate_fn=ds.collate)
+    else:
+        # test manifest of the YAML (data.path / test_manifest / test_labels): raw samples, features on the device
+        from avllm.data import create_dataloaders
+        from avllm.preprocess import ClipFrames, WhisperLogMel, device_collate
+        root = a.data_path or cfg.get("path") or "."
+        mp = os.path.join(root, a.test_manifest or cfg.get("test_manifest", "test.tsv"))
+        lp = os.path.join(root, a.test_labels or cfg.get("test_labels", "test.wrd"))
+        dl, _ = create_dataloaders(mp, lp, root, model.tokenizer, batch_size=a.batch_size, modality=a.modality, shuffle=False)
+        feats = (WhisperLogMel("cuda:0"), ClipFrames("cuda:0", image=model.cfg.clip.image))
+
+        def batches_from_files():
+            for b in dl:
+                audio, video = device_collate(b["raw"], *feats)
+                yield audio, video, b["texts"], b["labels"]
+        batches = batches_from_files()
     os.makedirs(a.output_dir, exist_ok=True)
     ts = time.strftime("%Y%m%d_%H%M%S")
     refs, hyps = [], []
     with open(os.path.join(a.output_dir, f"results_{ts}.txt"), "w") as f:
-        for audio, video, texts, _ in dl:
-            ids = model.generate(audio=audio.cuda() if a.modality != "video" else None, video=video.cuda() if a.modality != "audio" else None,
+        for audio, video, texts, _ in batches:
+            audio = audio if audio is None or a.modality == "video" else audio.cuda()
+            video = video if video is None or a.modality == "audio" else video.cuda()
+            ids = model.generate(audio=audio if a.modality != "video" else None, video=video if a.modality != "audio" else None,
                                  max_new_tokens=a.max_new_tokens, temperature=a.temperature)
             out = model.tokenizer.batch_decode(ids.cpu(), skip_special_tokens=True)
             for r, h in zip(texts, out):

@@ -37,3 +37,31 @@ def test_training_step_from_files_matches_oracle(dev, tmp_path):
     ref_loss, _, _ = O.train_step_grads(W, oc, ref_a, ref_v, prompt, labels)
     loss = tr.train_step(audio, video, labels, prompt)
     assert abs(float(loss) - float(ref_loss)) < 2e-4
+
+
+def test_cli_train_then_decode_from_manifests(dev, tmp_path):
+    """scripts/clip_whisper/train.py and decode.py on a toy LRS3-style directory: files -> device features -> LoRA steps ->
+    model_final.pt with the reference's checkpoint keys -> greedy decode -> results / WER files (train.py:35-80, decode.py:42-66)."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = tmp_path / "toy"
+    data.mkdir()
+    mp, lp = make_set(data, n=4)
+    (data / "test.tsv").write_text(mp.read_text()); (data / "test.wrd").write_text(lp.read_text())
+    out, dec = tmp_path / "out", tmp_path / "dec"
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts/clip_whisper/train.py"), "--tiny", "--data_path", str(data), "--batch_size", "2",
+                        "--max_epochs", "1", "--output_dir", str(out)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck = torch.load(out / "model_final.pt", map_location="cpu", weights_only=True)
+    keys = ck["model_state_dict"].keys()
+    assert "audio_connector.linear.weight" in keys and any(k.endswith("self_attn.q_proj.lora_A.default.weight") for k in keys)
+    assert os.path.exists(out / "training.log")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts/clip_whisper/decode.py"), "--tiny", "--data_path", str(data), "--batch_size", "2",
+                        "--max_new_tokens", "4", "--model_path", str(out / "model_final.pt"), "--output_dir", str(dec)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "corpus WER" in r.stdout and glob.glob(str(dec / "results_*.txt")) and glob.glob(str(dec / "wer_*.txt"))
