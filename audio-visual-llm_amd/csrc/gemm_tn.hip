@@ -5,6 +5,7 @@
 // Grid: (NB/128, M-chunks); fp32 atomics accumulate the chunk partials (<= 32 adders per element).
 #include "common.h"
 #include "avllm_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,12 +38,29 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // software pipeline: the next 64-row slab travels global -> registers while the MFMAs of the current one run
+    constexpr int BIG_PER_THREAD = TN_M * (TN_N / 8) / 256;       // 4 16-byte chunks of the wide operand per thread and slab
+    u32x4 nb[BIG_PER_THREAD], ns = {0u, 0u, 0u, 0u};
+    auto fetch = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < BIG_PER_THREAD; ++i) {
+            const int c = tid + i * 256, row = c >> 4, ch = c & 15;
+            nb[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (mb + row < m_end) nb[i] = *(const u32x4*)(Big + (long)(mb + row) * ldb + n0 + ch * 8);
+        }
+        if (tid < TN_M * 2) {
+            const int row = tid >> 1, ch = tid & 1;
+            ns = (u32x4){0u, 0u, 0u, 0u};
+            if (mb + row < m_end) ns = *(const u32x4*)(Small + (long)(mb + row) * lds_ + ch * 8);
+        }
+    };
+    if (m_begin < m_end) fetch(m_begin);
     for (int mb = m_begin; mb < m_end; mb += TN_M) {
         __syncthreads();
-        for (int c = tid; c < TN_M * (TN_N / 8); c += 256) {
-            const int row = c >> 4, ch = c & 15;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (mb + row < m_end) v = *(const u32x4*)(Big + (long)(mb + row) * ldb + n0 + ch * 8);
+#pragma unroll
+        for (int i = 0; i < BIG_PER_THREAD; ++i) {
+            const int c = tid + i * 256, row = c >> 4, ch = c & 15;
+            u32x4 v = nb[i];
             if (drop_p > 0.f) {          // Big = dropout(x): regenerate the forward's mask (index row*NB + col) instead of reading a copy
                 const bf16x8 xb = __builtin_bit_cast(bf16x8, v);
                 float f[8];
@@ -56,13 +74,9 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
             }
             *(u32x4*)(big_s + row * BIG_STRIDE + ch * 16) = v;
         }
-        if (tid < TN_M * 2) {
-            const int row = tid >> 1, ch = tid & 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (mb + row < m_end) v = *(const u32x4*)(Small + (long)(mb + row) * lds_ + ch * 8);
-            *(u32x4*)(small_s + row * SM_STRIDE + ch * 16) = v;
-        }
+        if (tid < TN_M * 2) *(u32x4*)(small_s + (tid >> 1) * SM_STRIDE + (tid & 1) * 16) = ns;
         __syncthreads();
+        if (mb + TN_M < m_end) fetch(mb + TN_M);
 #pragma unroll
         for (int ks = 0; ks < TN_M / 32; ++ks) {
             const bf16x8 sa = tr_frag16(small_s, SM_STRIDE, 32 * ks, 0, lane);                   // A: rows j, k = m
@@ -93,7 +107,11 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
 // Big [M,NB] (NB % 128 == 0), Small [M,>=16 cols, R valid]; out [NB,R] (TRANS_OUT=0) or [R,NB] (TRANS_OUT=1)
 int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
                     int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p) {
-    int zs = av_cdiv(M, 256);
+    // token chunks: enough workgroups to fill the chip (NB/128 x zs >= 256) but as few atomic adders per element as that allows
+    static const int chunk_env = getenv("AVLLM_TN_CHUNK") ? atoi(getenv("AVLLM_TN_CHUNK")) : 0;
+    // [NB,R] output = 64-byte rows scattered across lanes (slow atomics): fewer, longer chunks (measured 13.8 vs 18.3 us at 512 vs 256)
+    const int want = chunk_env > 0 ? chunk_env : (trans_out ? 256 : 512);
+    int zs = av_cdiv(M, want);
     zs = zs > 32 ? 32 : zs;
     int mchunk = av_cdiv(M, zs);
     mchunk = (mchunk + TN_M - 1) / TN_M * TN_M;

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Times the LoRA-side kernels on the bench shapes (M = 4096 tokens, d = 4096, rank 16 padded to 64; bf16)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-visual-llm_amd"))
+import torch
+from avllm import ops
+
+
+def timed(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1000
+
+
+dev, M, d = "cuda", 4096, 4096
+x = torch.randn(M, d, device=dev, dtype=torch.bfloat16)
+A = torch.randn(64, d, device=dev, dtype=torch.bfloat16) * 0.02
+t = torch.randn(M, 64, device=dev, dtype=torch.bfloat16)
+out = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
+print(f"rank-side GEMM t = x.A^T           {timed(lambda: ops.gemm(x, A, out=out)):7.1f} us   (x: 32 MiB)")
+print(f"rank-side GEMM with fused dropout  {timed(lambda: ops.gemm(x, A, out=out, a_drop=(7, 0.05))):7.1f} us")
+gB = torch.zeros(d, 16, device=dev)
+print(f"dB = dY^T.t   [4096,16]            {timed(lambda: ops.gemm_tn(x, t, gB, J=16)):7.1f} us")
+gA = torch.zeros(16, d, device=dev)
+print(f"dA = dt^T.x   [16,4096]            {timed(lambda: ops.gemm_tn(t, x, gA, I=16)):7.1f} us")
+print(f"dA with fused dropout              {timed(lambda: ops.gemm_tn(t, x, gA, I=16, drop=(7, 0.05))):7.1f} us")
