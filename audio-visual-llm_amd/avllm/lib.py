@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("A2", vp), ("B2", vp), ("C", vp), ("bias", vp), ("R", vp),
                 ("lda", i64), ("ldb", i64), ("lda2", i64), ("ldb2", i64), ("ldc", i64), ("ldr", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("K2", i32), ("dtype", i32), ("out_f32", i32), ("act", i32),
-                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32), ("a_drop_seed", C.c_uint32), ("a_drop_p", f32)]
+                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32), ("a_drop_seed", C.c_uint32), ("a_drop_p", f32), ("n_valid", i32)]
 
 
 class EncLayer(C.Structure):

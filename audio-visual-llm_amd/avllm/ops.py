@@ -15,7 +15,7 @@ def _ld(t):
 
 
 def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, alpha=1.0, out_f32=False,
-         r_mod=0, remap=None, M=None, a_drop=None):
+         r_mod=0, remap=None, M=None, a_drop=None, n_valid=0):
     """out[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias) + R.  A [M,K] (row stride free), B [N,K].
     a_drop=(seed, p): A is replaced by dropout(A) on the fly (bf16, N == 64 only)."""
     lib = L.load()
@@ -39,6 +39,7 @@ def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, al
         d.g_in, d.g_out, d.g_off = remap
     if a_drop is not None:
         d.a_drop_seed, d.a_drop_p = a_drop[0] & 0xFFFFFFFF, a_drop[1]
+    d.n_valid = n_valid
     L.check(lib.avllm_gemm(C.byref(d), L.stream_ptr()))
     return out
 

@@ -188,6 +188,7 @@ int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long
         g = gemm_desc(m->dtype, xl ? xl : x, xl ? (long)K : ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
         g.alpha = m->lora_scale;
         g.a_drop_seed = a_seed; g.a_drop_p = a_p;      // bf16: dropout generated inside the rank-side GEMM
+        g.n_valid = m->lora_r;                         // rank padded to 64: the padding columns are written as zeros, not computed
         AV_TRY(av_gemm(&g, st));
     }
     g = gemm_desc(m->dtype, x, ldx, W, ldw, y, ldy, M, N, K);
@@ -374,7 +375,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
         if (lo.A_pad) {
             AV_TRY(av_gemm_tn(w.dres, d, d, a.to, AVLLM_LORA_PAD, R, M, lo.gB, R, 1.0f, dt, st));
             avllm_gemm_desc gt = gemm_desc(dt, w.dres, d, lo.BT_pad, d, w.dto, AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, d);
-            gt.alpha = sc;
+            gt.alpha = sc; gt.n_valid = R;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.att;
             if (drop && !fuse_drop) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xin = w.xd; }
@@ -406,7 +407,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             char* dtj = (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es;
             AV_TRY(av_gemm_tn(dy, qw, wj, (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD, R, M, lj.gB, R, 1.0f, dt, st));
             avllm_gemm_desc gt = gemm_desc(dt, dy, qw, lj.BT_pad, wj, dtj, 3 * AVLLM_LORA_PAD, M, AVLLM_LORA_PAD, wj);
-            gt.alpha = sc;
+            gt.alpha = sc; gt.n_valid = R;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.xn1;
             if (drop && !fuse_drop) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xin = w.xd; }

@@ -514,11 +514,13 @@ __device__ __forceinline__ bf16x8 drop_frag(bf16x8 x, uint32_t seed, unsigned lo
 
 // DROP: the A operand is dropout(A) with the library's counter-based mask over the logical index row*K + col (A must be the
 // full [M,K] activation) -- peft's lora_A(dropout(x)) without materialising dropout(x).
-template <bool DROP>
+// NV = 16-column tiles that hold real rank columns (rank 16 padded to 64 -> NV = 1): only those weight rows are streamed and
+// multiplied, the padding columns of the output are written as zeros.
+template <bool DROP, int NV>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B,
                                                                       long ldb, int M, int K, float alpha, void* __restrict__ C, long ldc,
                                                                       int out_f32, uint32_t seed, float p) {
-    __shared__ float part[SK_WAVES][16][65];
+    __shared__ float part[SK_WAVES][16][NV * 16 + 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.x * 16;
@@ -526,40 +528,41 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16
     const int kw = K / SK_WAVES;                    // multiple of 32
     const bf16* ap = A + (long)ar * lda + (long)w * kw + fq * 8;
     const bf16* bp = B + (long)fr * ldb + (long)w * kw + fq * 8;
-    f32x4 acc[4];
+    f32x4 acc[NV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // explicit 4-deep software unroll (the pragma form is rejected for the runtime trip count): 20 independent 16-byte loads
-    // are issued before the first MFMA of a group consumes one, which is what hides the HBM/L2 latency here
+    for (int j = 0; j < NV; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // explicit software unroll (the pragma form is rejected for the runtime trip count): 16-20 independent 16-byte loads are
+    // issued before the first MFMA of a group consumes one, which is what hides the HBM/L2 latency here
+    constexpr int UNR = NV == 1 ? 8 : 4;
     const uint32_t thr = av_drop_thr(p);
     const float dsc = av_drop_scale(p);
     const unsigned long long idx_base = (unsigned long long)ar * K + (unsigned long long)w * kw + fq * 8;
     int k = 0;
-    for (; k + 128 <= kw; k += 128) {
-        bf16x8 xa[4], wb[4][4];
+    for (; k + 32 * UNR <= kw; k += 32 * UNR) {
+        bf16x8 xa[UNR], wb[UNR][NV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             xa[u] = *(const bf16x8*)(ap + k + 32 * u);
             if (DROP) xa[u] = drop_frag(xa[u], seed, idx_base + k + 32 * u, thr, dsc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wb[u][j] = *(const bf16x8*)(bp + (long)j * 16 * ldb + k + 32 * u);
+            for (int j = 0; j < NV; ++j) wb[u][j] = *(const bf16x8*)(bp + (long)j * 16 * ldb + k + 32 * u);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u][j], xa[u], acc[j], 0, 0, 0);     // D[n][m]
+            for (int j = 0; j < NV; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u][j], xa[u], acc[j], 0, 0, 0);     // D[n][m]
     }
     for (; k < kw; k += 32) {
         bf16x8 xa = *(const bf16x8*)(ap + k);
         if (DROP) xa = drop_frag(xa, seed, idx_base + k, thr, dsc);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const bf16x8 wb = *(const bf16x8*)(bp + (long)j * 16 * ldb + k);
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc[j], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[w][fr][j * 16 + fq * 4 + i] = acc[j][i];
     __syncthreads();
@@ -567,9 +570,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16
         const int r = e >> 6, c = e & 63;
         if (m0 + r >= M) continue;
         float s = 0.f;
+        if (c < NV * 16) {
 #pragma unroll
-        for (int x = 0; x < SK_WAVES; ++x) s += part[x][r][c];
-        s *= alpha;
+            for (int x = 0; x < SK_WAVES; ++x) s += part[x][r][c];
+            s *= alpha;
+        }
         if (out_f32) ((float*)C)[(long)(m0 + r) * ldc + c] = s;
         else ((bf16*)C)[(long)(m0 + r) * ldc + c] = (bf16)s;
     }
@@ -724,12 +729,20 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     } else if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
                d->K % (32 * SK_WAVES) == 0 && (d->M >= 256 || d->a_drop_p > 0.f)) {
         AV_CHECK_ARG(d->a_drop_p <= 0.f || d->lda == d->K, "gemm: a_drop needs the full contiguous [M,K] activation as A");
-        if (d->a_drop_p > 0.f)
-            hipLaunchKernelGGL((gemm_skinny64_kernel<true>), dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
-                               (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, d->a_drop_seed, d->a_drop_p);
-        else
-            hipLaunchKernelGGL((gemm_skinny64_kernel<false>), dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, (const bf16*)d->A, d->lda,
-                               (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, 0u, 0.f);
+        AV_CHECK_ARG(d->n_valid >= 0 && d->n_valid <= 64, "gemm: n_valid=%d", d->n_valid);
+        const int nv = d->n_valid > 0 ? (d->n_valid + 15) / 16 : 4;
+#define AV_SKINNY(DROPV, NVV, SEED, P) hipLaunchKernelGGL((gemm_skinny64_kernel<DROPV, NVV>), dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, \
+            (const bf16*)d->A, d->lda, (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, SEED, P)
+        if (d->a_drop_p > 0.f) {
+            if (nv == 1) AV_SKINNY(true, 1, d->a_drop_seed, d->a_drop_p);
+            else if (nv == 2) AV_SKINNY(true, 2, d->a_drop_seed, d->a_drop_p);
+            else AV_SKINNY(true, 4, d->a_drop_seed, d->a_drop_p);
+        } else {
+            if (nv == 1) AV_SKINNY(false, 1, 0u, 0.f);
+            else if (nv == 2) AV_SKINNY(false, 2, 0u, 0.f);
+            else AV_SKINNY(false, 4, 0u, 0.f);
+        }
+#undef AV_SKINNY
     } else if (d->a_drop_p > 0.f) {
         return av_set_error(AV_ERR_UNSUPPORTED, "gemm: a_drop_p is only implemented by the bf16 N==64 rank-side kernel (K %% 256 == 0)");
     } else if (d->dtype == AV_BF16) {

@@ -54,6 +54,8 @@ typedef struct avllm_gemm_desc {
     float drop_p;                       /*   keep(drop_seed, m*N+n, p)/(1-p)  -- see avllm_dropout */
     uint32_t a_drop_seed;               /* a_drop_p>0: the A operand is dropout(A), mask index m*K+k (bf16, N==64 rank-side GEMM only): */
     float a_drop_p;                     /*   peft's lora_A(dropout(x)) without materialising dropout(x) */
+    int32_t n_valid;                    /* N == 64 rank-side GEMM: only rows [0,n_valid) of B are non-zero (rank padded to 64); the other
+                                         * output columns are written as zeros without being computed.  0 = all N */
 } avllm_gemm_desc;
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
 /* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT) */

@@ -22,6 +22,23 @@ def test_gemm_skinny_n64(dev, M, K):
     assert dst[:, :64].abs().max().item() == 0 and dst[:, 128:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("r", [16, 32, 8])
+def test_gemm_skinny_n_valid(dev, r):
+    """Rank padded to 64: with n_valid = r only the real rank rows of the weight image are streamed; the padding columns come out as
+    exact zeros and the real ones are identical to the full computation."""
+    M, K = 4096, 4096
+    x = rnd(M, K, dtype=torch.bfloat16, seed=41)
+    A = torch.zeros(64, K, device=dev, dtype=torch.bfloat16)
+    A[:r] = rnd(r, K, dtype=torch.bfloat16, seed=42)
+    full = ops.gemm(x, A, alpha=2.0)
+    part = ops.gemm(x, A, alpha=2.0, n_valid=r)
+    nv = (r + 15) // 16 * 16
+    assert torch.equal(part[:, :nv], full[:, :nv]) and float(part[:, nv:].abs().max() if nv < 64 else 0.0) == 0.0
+    pd = ops.gemm(x, A, alpha=2.0, n_valid=r, a_drop=(9, 0.05))
+    fd = ops.gemm(ops.dropout(x, 9, 0.05), A, alpha=2.0)
+    assert torch.equal(pd[:, :nv], fd[:, :nv])
+
+
 @pytest.mark.parametrize("M,NB", [(2048, 4096), (1000, 256), (70, 128)])
 def test_gemm_tn_mfma(dev, M, NB):
     big = rnd(M, NB, dtype=torch.bfloat16, seed=4)

@@ -26,6 +26,7 @@ t = torch.randn(M, 64, device=dev, dtype=torch.bfloat16)
 out = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
 print(f"rank-side GEMM t = x.A^T           {timed(lambda: ops.gemm(x, A, out=out)):7.1f} us   (x: 32 MiB)")
 print(f"rank-side GEMM with fused dropout  {timed(lambda: ops.gemm(x, A, out=out, a_drop=(7, 0.05))):7.1f} us")
+print(f"  ... only the 16 real rank columns {timed(lambda: ops.gemm(x, A, out=out, n_valid=16)):7.1f} us   with dropout {timed(lambda: ops.gemm(x, A, out=out, a_drop=(7, 0.05), n_valid=16)):7.1f} us")
 gB = torch.zeros(d, 16, device=dev)
 print(f"dB = dY^T.t   [4096,16]            {timed(lambda: ops.gemm_tn(x, t, gB, J=16)):7.1f} us")
 gA = torch.zeros(16, d, device=dev)
