@@ -33,7 +33,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int stride, int row0,
 }
 
 // Tiles go global -> registers -> LDS: the loads of the NEXT tile are issued right after the current tile has been written to
-// LDS, so their latency runs under the current tile's MFMA work (these kernels hold one workgroup per CU: nothing else hides it).
+// LDS, so their latency runs under the current tile's MFMA work.  Both kernels are held to 256 registers (two waves per SIMD, i.e.
+// two workgroups per CU): left alone hipcc takes ~400 and a lone wave per SIMD exposes every barrier and LDS round trip.
 template <int HD, int NT, int ROWS> struct RowRegs { u32x4 v[(ROWS * (HD / 8) + NT - 1) / NT]; };
 
 template <int HD, int NT, int ROWS>
@@ -61,7 +62,7 @@ __device__ __forceinline__ void store_rows(const RowRegs<HD, NT, ROWS>& r, char*
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <int HD, int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                             const bf16* __restrict__ v, const bf16* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16* __restrict__ dq, int T, int H, long ldq, long ldk, long ldv,
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_mfma(const bf16* __restri
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int HD, int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                              const bf16* __restrict__ v, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int T, int H, long ldq,
