@@ -325,17 +325,33 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;
+    // Staging addresses: this thread's four loads (row groups wave and 16+wave of A and of B) keep their element offsets
+    // row*ld + swizzled chunk in registers for both K segments, so a K-tile costs one 64-bit add per load instead of a
+    // 64-bit multiply chain (32-bit offsets: the dispatcher only sends operands below 2^32 elements here).
+    const int rsub = lane >> 3, swz = ((lane & 7) ^ rsub) << 3;
+    unsigned offA0[2], offA1[2], offB0[2], offB1[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int ra = m0 + (p * 16 + wave) * 8 + rsub, rb = n0 + (p * 16 + wave) * 8 + rsub;
+        ra = ra < g.e.M ? ra : g.e.M - 1;                     // rows past the edge are never stored
+        rb = rb < g.e.N ? rb : g.e.N - 1;
+        offA0[p] = (unsigned)ra * (unsigned)g.lda + swz; offA1[p] = (unsigned)ra * (unsigned)g.lda2 + swz;
+        offB0[p] = (unsigned)rb * (unsigned)g.ldb + swz; offB1[p] = (unsigned)rb * (unsigned)g.ldb2 + swz;
+    }
     auto stage = [&](int t, int buf) {
         char* a_lds = smem + buf * HSTAGE;
         char* b_lds = a_lds + HBM_ * BK * 2;
-        const bf16* Ap = t < nt1 ? g.A : g.A2;
-        const bf16* Bp = t < nt1 ? g.B : g.B2;
-        const long la = t < nt1 ? g.lda : g.lda2, lb = t < nt1 ? g.ldb : g.ldb2;
-        const int k0 = (t < nt1 ? t : t - nt1) * BK;
+        const bool seg2 = t >= nt1;
+        const bf16* Ap = (seg2 ? g.A2 : g.A) + (seg2 ? t - nt1 : t) * BK;
+        const bf16* Bp = (seg2 ? g.B2 : g.B) + (seg2 ? t - nt1 : t) * BK;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows8(Ap, la, m0, g.e.M, k0, a_lds, p * 16 + wave, lane);     // 32 groups = 256 rows
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + (seg2 ? offA1[p] : offA0[p])),
+                                             (__attribute__((address_space(3))) void*)(a_lds + (p * 16 + wave) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) stage_rows8(Bp, lb, n0, g.e.N, k0, b_lds, p * 16 + wave, lane);
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bp + (seg2 ? offB1[p] : offB0[p])),
+                                             (__attribute__((address_space(3))) void*)(b_lds + (p * 16 + wave) * 1024), 16, 0, 0);
     };
 
     stage(0, 0);
@@ -761,9 +777,13 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         const int xtiles = av_cdiv(d->M, XBM) * av_cdiv(d->N, XBN);
         // automatic choice (tools/gemm_bench.py on MI355X): 256x256 / 16 waves whenever it fills the chip, 256x128 ring for very
         // long K with few tiles, else 128x128 with two workgroups per CU
-        const bool auto_h = variant == 0 && xtiles >= 200;
+        // the 16-wave kernel keeps 32-bit element offsets of its staging rows: operands must stay below 2^32 elements
+        const bool fits32 = (double)d->M * (double)(d->lda > d->lda2 ? d->lda : d->lda2) < 4.0e9 &&
+                            (double)d->N * (double)(d->ldb > d->ldb2 ? d->ldb : d->ldb2) < 4.0e9;
+        const bool auto_h = variant == 0 && xtiles >= 200 && fits32;
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
         if (d->M > 128 && (variant == 5 || variant == 6 || auto_h)) {
+            AV_CHECK_ARG(fits32 || variant == 6, "gemm: operand too large for the 256x256 kernel's 32-bit row offsets");
             static bool attr4 = false;
             if (!attr4) {
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE));
