@@ -269,17 +269,20 @@ class LlamaEngine:
             v[k].copy_(t.to(device=self.device, dtype=torch.float32))
 
     def pack_lora(self):
-        """Refresh the padded operand images from the fp32 masters (after every optimizer step)."""
+        """Refresh the padded operand images from the fp32 masters (after every optimizer step): one launch for all adapters,
+        driven by a device-side table of (master, image) pointers built on first use."""
         lib = L.load()
-        r, d = self.r, self.cfg.hidden
-        st = L.stream_ptr()
-        dt = self.desc.dtype
-        for i in range(self.cfg.layers):
-            for j in range(4):
-                a, b = self._slices(i, j)
-                lm = self.layers[i].lora[j]
-                L.check(lib.avllm_lora_pack(self.lora_p[a[0]:a[1]].data_ptr(), self.lora_p[b[0]:b[1]].data_ptr(), r, d, self.douts[j],
-                                            lm.A_pad, lm.AT_pad, lm.ld_at, lm.B_pad, lm.BT_pad, dt, st))
+        if getattr(self, "_pack_table", None) is None:
+            rows = []
+            for i in range(self.cfg.layers):
+                for j in range(4):
+                    a, b = self._slices(i, j)
+                    lm = self.layers[i].lora[j]
+                    rows.append([self.lora_p[a[0]:a[1]].data_ptr(), self.lora_p[b[0]:b[1]].data_ptr(), lm.A_pad, lm.AT_pad, lm.B_pad, lm.BT_pad,
+                                 lm.ld_at, self.douts[j]])
+            self._pack_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        L.check(lib.avllm_lora_pack_batch(L.ptr(self._pack_table), self._pack_table.shape[0], self.r, self.cfg.hidden, self.desc.dtype,
+                                          L.stream_ptr()))
 
     # ------------------------------------------------------------------ training
     def fwd_loss(self, x, labels, want_logits=False, dropout=0.0, seed=0):

@@ -76,6 +76,7 @@ _SIGS = {
     "avllm_clip_preproc_plan_init": ([vp, i32, i32, i32, vp, vp], i32),
     "avllm_clip_preproc_workspace_bytes": ([i32, i32, i32, i32], C.c_size_t),
     "avllm_clip_preproc": ([vp, vp, i32, i32, i32, i32, vp, i32, vp, C.c_size_t, vp], i32),
+    "avllm_lora_pack_batch": ([vp, i32, i32, i32, i32, vp], i32),
     "avllm_layernorm": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_fwd": ([vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     "avllm_rmsnorm_bwd": ([vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),

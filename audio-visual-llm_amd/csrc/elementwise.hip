@@ -298,6 +298,29 @@ __global__ void lora_pack_kernel(const float* __restrict__ A, const float* __res
     }
 }
 
+// every adapter of the model in ONE launch: blockIdx.x = module (table row in device memory), blockIdx.y strides over its elements
+template <typename T>
+__global__ void lora_pack_batch_kernel(const avllm_lora_pack_item* __restrict__ items, int r, int din) {
+    const avllm_lora_pack_item it = items[blockIdx.x];
+    const int dout = (int)it.dout;
+    const long nA = (long)AVLLM_LORA_PAD * din, nB = (long)AVLLM_LORA_PAD * dout;
+    T* A_pad = (T*)it.A_pad; T* AT_pad = (T*)it.AT_pad; T* B_pad = (T*)it.B_pad; T* BT_pad = (T*)it.BT_pad;
+    for (long idx = blockIdx.y * (long)blockDim.x + threadIdx.x; idx < nA + nB; idx += (long)gridDim.y * blockDim.x) {
+        if (idx < nA) {
+            const int j = (int)(idx / din), k = (int)(idx % din);
+            const float val = j < r ? it.A[(long)j * din + k] : 0.f;
+            A_pad[(long)j * din + k] = from_f<T>(val);
+            AT_pad[(long)k * it.ld_at + j] = from_f<T>(val);
+        } else {
+            const long i2 = idx - nA;
+            const int j = (int)(i2 / dout), n = (int)(i2 % dout);
+            const float val = j < r ? it.B[(long)n * r + j] : 0.f;
+            BT_pad[(long)j * dout + n] = from_f<T>(val);
+            B_pad[(long)n * AVLLM_LORA_PAD + j] = from_f<T>(val);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- KV cache append: cache[b, pos0+t, :] = k[b*T+t, :]
 template <typename T>
 __global__ void kv_append_kernel(const T* __restrict__ k, const T* __restrict__ v, long ld, T* __restrict__ kc, T* __restrict__ vc,
@@ -457,6 +480,16 @@ int av_lora_pack(const float* A, const float* Bm, int r, int din, int dout, void
     const long total = (long)AVLLM_LORA_PAD * (din + dout);
     if (dtype == AV_F32) hipLaunchKernelGGL((lora_pack_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, A, Bm, r, din, dout, (float*)A_pad, (float*)AT_pad, ld_at, (float*)B_pad, (float*)BT_pad);
     else hipLaunchKernelGGL((lora_pack_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, A, Bm, r, din, dout, (bf16*)A_pad, (bf16*)AT_pad, ld_at, (bf16*)B_pad, (bf16*)BT_pad);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int avllm_lora_pack_batch(const avllm_lora_pack_item* items_dev, int32_t n, int32_t r, int32_t din, int32_t dtype, void* stream) {
+    AV_CHECK_ARG(items_dev && n > 0 && din > 0, "lora_pack_batch: null/empty");
+    AV_CHECK_ARG(r > 0 && r <= AVLLM_LORA_PAD, "lora_pack_batch: rank %d > %d unsupported", r, AVLLM_LORA_PAD);
+    const dim3 grid(n, 16);
+    if (dtype == AV_F32) hipLaunchKernelGGL((lora_pack_batch_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, items_dev, r, din);
+    else hipLaunchKernelGGL((lora_pack_batch_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, items_dev, r, din);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
