@@ -6,6 +6,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from avllm import ops  # noqa: E402
+from avllm.lib import ACT_GELU as L_ACT_GELU  # noqa: E402
 from test_ops_gpu import close, rnd  # noqa: E402
 
 
@@ -20,6 +21,23 @@ def test_gemm_skinny_n64(dev, M, K):
     ops.gemm(A, B, out=dst[:, 64:128])                       # strided destination (column slice)
     close(dst[:, 64:128], A.float() @ B.float().t(), 0.05 * (K ** 0.5) / 8, 2e-2, "skinny gemm slice")
     assert dst[:, :64].abs().max().item() == 0 and dst[:, 128:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,N,K,how", [(4096, 22016, 256, "cols"), (9000, 768, 128, "rows"), (24000, 2304, 64, "rows"), (4100, 22016, 64, "cols")])
+def test_gemm_large_grids_with_fused_epilogue(dev, M, N, K, how):
+    """Large ragged tile grids (tile counts just above a multiple of the CU count, edge tiles in M) with bias + GELU + residual and
+    with the LoRA second K segment, against torch."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=51)
+    B = rnd(N, K, dtype=torch.bfloat16, seed=52, scale=K ** -0.5)
+    bias = rnd(N, dtype=torch.bfloat16, seed=53)
+    R = rnd(M, N, dtype=torch.bfloat16, seed=54)
+    out = ops.gemm(A, B, bias=bias, R=R, act=L_ACT_GELU)
+    ref = torch.nn.functional.gelu(A.float() @ B.float().t() + bias.float()) + R.float()
+    close(out, ref, 4e-2, 2e-2, f"large-grid gemm ({how})")
+    # LoRA second K segment through both parts
+    A2, B2 = rnd(M, 64, dtype=torch.bfloat16, seed=55), rnd(N, 64, dtype=torch.bfloat16, seed=56, scale=0.1)
+    out2 = ops.gemm(A, B, A2=A2, B2=B2)
+    close(out2, A.float() @ B.float().t() + A2.float() @ B2.float().t(), 4e-2, 2e-2, "large-grid gemm with K2")
 
 
 @pytest.mark.parametrize("r", [16, 32, 8])
