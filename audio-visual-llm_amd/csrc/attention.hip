@@ -12,6 +12,7 @@
 // ds_read_b128 row reads and the 4-row transposed reads bank-conflict free (MI355X_MICROARCH §LDS).
 #include "common.h"
 #include "avllm_internal.h"
+#include <cstdlib>
 
 int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
                          int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st, int G);
@@ -29,7 +30,7 @@ typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-template <int HD, int NW, bool CAUSAL>
+template <int HD, int NW, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                          const bf16* __restrict__ v, bf16* __restrict__ o, float* __restrict__ lse,
                                                          int Tq, int Tk, int H, long ldq, long ldk, long ldv, long ldo,
@@ -92,20 +93,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
         }
     };
     if (ONESHOT) {
-        for (int c = tid; c < LROWS * CPR; c += NT) {
-            const int row = c / CPR, ch = c % CPR;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (row < Tk) {
-                kv = *(const u32x4*)(k + ((long)b * Tk + row) * ldk + (long)hk * HD + ch * 8);
-                vv = *(const u32x4*)(v + ((long)b * Tk + row) * ldv + (long)hk * HD + ch * 8);
+        // every global load of the K/V image is issued before the first LDS store waits on one: a single exposed latency
+        constexpr int NONE = (LROWS * CPR + NT - 1) / NT;
+        u32x4 kall[NONE], vall[NONE];
+#pragma unroll
+        for (int i = 0; i < NONE; ++i) {
+            const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
+            kall[i] = (u32x4){0u, 0u, 0u, 0u}; vall[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (!(ABL & 2) && c < LROWS * CPR && row < Tk) {
+                kall[i] = *(const u32x4*)(k + ((long)b * Tk + row) * ldk + (long)hk * HD + ch * 8);
+                vall[i] = *(const u32x4*)(v + ((long)b * Tk + row) * ldv + (long)hk * HD + ch * 8);
             }
-            *(u32x4*)(k_lds + row * KS + ch * 16) = kv;
-            *(u32x4*)(v_lds + row * VS + ch * 16) = vv;
+        }
+#pragma unroll
+        for (int i = 0; i < NONE; ++i) {
+            const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
+            if (c < LROWS * CPR) {
+                *(u32x4*)(k_lds + row * KS + ch * 16) = kall[i];
+                *(u32x4*)(v_lds + row * VS + ch * 16) = vall[i];
+            }
         }
         __syncthreads();
     }
     if (PREFETCH) prefetch(0);
-    for (int kb = 0; kb < k_end; kb += 64) {
+    for (int kb = 0; kb < ((ABL & 1) ? 0 : k_end); kb += 64) {
         const int lrow0 = ONESHOT ? kb : 0;        // first LDS row of this 64-key step
         if (!ONESHOT) {
             if (!PREFETCH) prefetch(kb);
@@ -157,12 +168,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32)) * scale_log2e;
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            s0[i] = exp2f(fmaf(s0[i], scale_log2e, -m_use));
-            s1[i] = exp2f(fmaf(s1[i], scale_log2e, -m_use));
+            s0[i] = __builtin_amdgcn_exp2f(fmaf(s0[i], scale_log2e, -m_use));
+            s1[i] = __builtin_amdgcn_exp2f(fmaf(s1[i], scale_log2e, -m_use));
             psum += s0[i] + s1[i];
         }
         l_run = l_run * alpha + psum;
@@ -196,6 +207,31 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
                 }
             }
         }
+    }
+    if (ONESHOT) {
+        // Output through LDS: the MFMA layout gives every lane 8-byte pieces of 32 different rows (64 scattered stores per
+        // instruction); parked in the (now free) K image as bf16 rows, the wave's 32 x HD tile leaves as whole 16-byte row chunks.
+        __syncthreads();                                       // every wave is done reading K/V
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        char* ot = k_lds + w * 32 * KS;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float vals[4] = {oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv, oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv};
+                store_f<4>((bf16*)(ot + r * KS) + 32 * d + 8 * g4 + 4 * half, vals);
+            }
+        if (lse && half == 0 && qpos < Tq) lse[((long)b * H + hh) * Tq + qpos] = (m_run + log2f(l_tot)) * 0.69314718055994531f;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 32 * CPR / 64; ++i) {
+            const int c = lane + i * 64, row = c / CPR, ch = c % CPR;
+            if (!(ABL & 4) && q0 + row < Tq)
+                *(u32x4*)(o + ((long)b * Tq + q0 + row) * ldo + (long)hh * HD + ch * 8) = *(const u32x4*)(ot + row * KS + ch * 16);
+        }
+        return;
     }
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -239,7 +275,18 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
         return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st, G);
     if (hd == 64) {
         // short sequences (CLIP: 197 tokens): one workgroup covers the whole sequence with 7 waves
-        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
+        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) {
+            static const int abl = getenv("AVLLM_ATTN_ABL") ? atoi(getenv("AVLLM_ATTN_ABL")) : 0;
+            if (abl) {
+                const dim3 grid(av_cdiv(Tq, 32 * 7), H, B), block(7 * 64);
+                const float sl = scale * 1.4426950408889634f;
+#define AV_ABL(X) hipLaunchKernelGGL((attn_fwd_mfma<64, 7, false, X>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl, G)
+                if (abl == 1) AV_ABL(1); else if (abl == 2) AV_ABL(2); else if (abl == 3) AV_ABL(3); else if (abl == 4) AV_ABL(4); else if (abl == 6) AV_ABL(6); else AV_ABL(7);
+#undef AV_ABL
+                return AV_OK;
+            }
+            return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
+        }
         return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
     }
     return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);

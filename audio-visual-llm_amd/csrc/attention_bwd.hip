@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_mfma(const bf16* __res
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kb + 32 * sb + acc_row(i, half);
-                const float p = key <= klim ? exp2f(s[i] * sl - lse2) : 0.f;
+                const float p = key <= klim ? __builtin_amdgcn_exp2f(s[i] * sl - lse2) : 0.f;
                 s[i] = p * (dp[i] - dlt) * scale;                 // dS^T
             }
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
                 const int i = 4 * g4 + j;
                 const int qi = qb + 8 * g4 + 4 * half + j;
                 const bool ok = qi < T && kpos < T && (!CAUSAL || kpos <= qi);
-                const float pv = ok ? exp2f(s[i] * sl - l4[j]) : 0.f;
+                const float pv = ok ? __builtin_amdgcn_exp2f(s[i] * sl - l4[j]) : 0.f;
                 p[i] = pv;
                 s[i] = pv * (dp[i] - d4[j]) * scale;        // dS[query][key]
             }

@@ -140,11 +140,11 @@ __device__ __forceinline__ float act_apply_fast(float x, int act) {
             const float z = fabsf(x) * 0.70710678118654752f;
             const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
             const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-            const float erf_abs = 1.0f - poly * exp2f(-z * z * 1.4426950408889634f);
+            const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
             return 0.5f * x * (1.0f + copysignf(erf_abs, x));
         }
-        case AV_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + exp2f(-1.702f * 1.4426950408889634f * x));
-        case AV_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + exp2f(-1.4426950408889634f * x));
+        case AV_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+        case AV_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
         default: return x;
     }
 }
