@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-template <int HD, int NW, bool CAUSAL, int ABL = 0>
+template <int HD, int NW, bool CAUSAL>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                          const bf16* __restrict__ v, bf16* __restrict__ o, float* __restrict__ lse,
                                                          int Tq, int Tk, int H, long ldq, long ldk, long ldv, long ldo,
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
         for (int i = 0; i < NONE; ++i) {
             const int c = tid + i * NT, row = c / CPR, ch = c % CPR;
             kall[i] = (u32x4){0u, 0u, 0u, 0u}; vall[i] = (u32x4){0u, 0u, 0u, 0u};
-            if (!(ABL & 2) && c < LROWS * CPR && row < Tk) {
+            if (c < LROWS * CPR && row < Tk) {
                 kall[i] = *(const u32x4*)(k + ((long)b * Tk + row) * ldk + (long)hk * HD + ch * 8);
                 vall[i] = *(const u32x4*)(v + ((long)b * Tk + row) * ldv + (long)hk * HD + ch * 8);
             }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
         __syncthreads();
     }
     if (PREFETCH) prefetch(0);
-    for (int kb = 0; kb < ((ABL & 1) ? 0 : k_end); kb += 64) {
+    for (int kb = 0; kb < k_end; kb += 64) {
         const int lrow0 = ONESHOT ? kb : 0;        // first LDS row of this 64-key step
         if (!ONESHOT) {
             if (!PREFETCH) prefetch(kb);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
 #pragma unroll
         for (int i = 0; i < 32 * CPR / 64; ++i) {
             const int c = lane + i * 64, row = c / CPR, ch = c % CPR;
-            if (!(ABL & 4) && q0 + row < Tq)
+            if (q0 + row < Tq)
                 *(u32x4*)(o + ((long)b * Tq + q0 + row) * ldo + (long)hh * HD + ch * 8) = *(const u32x4*)(ot + row * KS + ch * 16);
         }
         return;
@@ -275,18 +275,7 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
         return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st, G);
     if (hd == 64) {
         // short sequences (CLIP: 197 tokens): one workgroup covers the whole sequence with 7 waves
-        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) {
-            static const int abl = getenv("AVLLM_ATTN_ABL") ? atoi(getenv("AVLLM_ATTN_ABL")) : 0;
-            if (abl) {
-                const dim3 grid(av_cdiv(Tq, 32 * 7), H, B), block(7 * 64);
-                const float sl = scale * 1.4426950408889634f;
-#define AV_ABL(X) hipLaunchKernelGGL((attn_fwd_mfma<64, 7, false, X>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, ldq, ldk, ldv, ldo, sl, G)
-                if (abl == 1) AV_ABL(1); else if (abl == 2) AV_ABL(2); else if (abl == 3) AV_ABL(3); else if (abl == 4) AV_ABL(4); else if (abl == 6) AV_ABL(6); else AV_ABL(7);
-#undef AV_ABL
-                return AV_OK;
-            }
-            return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
-        }
+        if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
         return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
     }
     return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
