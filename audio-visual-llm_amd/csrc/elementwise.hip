@@ -303,18 +303,19 @@ template <typename T>
 __global__ void lora_pack_batch_kernel(const avllm_lora_pack_item* __restrict__ items, int r, int din) {
     const avllm_lora_pack_item it = items[blockIdx.x];
     const int dout = (int)it.dout;
-    const long nA = (long)AVLLM_LORA_PAD * din, nB = (long)AVLLM_LORA_PAD * dout;
+    // only the r real rank rows/columns are rewritten: the padding up to AVLLM_LORA_PAD is zero from allocation and never changes
+    const long nA = (long)r * din, nB = (long)r * dout;
     T* A_pad = (T*)it.A_pad; T* AT_pad = (T*)it.AT_pad; T* B_pad = (T*)it.B_pad; T* BT_pad = (T*)it.BT_pad;
     for (long idx = blockIdx.y * (long)blockDim.x + threadIdx.x; idx < nA + nB; idx += (long)gridDim.y * blockDim.x) {
         if (idx < nA) {
             const int j = (int)(idx / din), k = (int)(idx % din);
-            const float val = j < r ? it.A[(long)j * din + k] : 0.f;
+            const float val = it.A[(long)j * din + k];
             A_pad[(long)j * din + k] = from_f<T>(val);
             AT_pad[(long)k * it.ld_at + j] = from_f<T>(val);
         } else {
             const long i2 = idx - nA;
             const int j = (int)(i2 / dout), n = (int)(i2 % dout);
-            const float val = j < r ? it.B[(long)n * r + j] : 0.f;
+            const float val = it.B[(long)n * r + j];
             BT_pad[(long)j * dout + n] = from_f<T>(val);
             B_pad[(long)n * AVLLM_LORA_PAD + j] = from_f<T>(val);
         }

@@ -141,7 +141,8 @@ int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, fl
  * A_pad [64,din], AT_pad [din,64] (row stride ld_at), B_pad [dout,64], BT_pad [64,dout] in `dtype` */
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,
                     int64_t ld_at, void* B_pad, void* BT_pad, int32_t dtype, void* stream);
-/* the same for every adapter of a model in one launch: `items_dev` is a table of n rows in DEVICE memory (built once) */
+/* the same for every adapter of a model in one launch: `items_dev` is a table of n rows in DEVICE memory (built once).
+ * Only the r real rank rows/columns are written: the images must be zero-initialised once (their padding never changes). */
 typedef struct avllm_lora_pack_item {
     const float *A, *B;              /* fp32 masters: A [r,din], B [dout,r] */
     void *A_pad, *AT_pad, *B_pad, *BT_pad;
