@@ -20,9 +20,9 @@ int av_attention_delta(const void* o, const void* dout, float* delta, int B, int
 int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                          void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
                          long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st, int G);
-int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G);
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G, const void* o, long ldo);
 
 namespace {
 
@@ -289,9 +289,9 @@ int av_attention_bwd(const void* q, const void* k, const void* v, const void* o,
     if (kv_heads <= 0) kv_heads = H;
     AV_CHECK_ARG(H % kv_heads == 0, "attention_bwd: %d query heads are not a multiple of %d key/value heads", H, kv_heads);
     const int G = H / kv_heads;
-    // dO shares O's row stride
-    AV_TRY(av_attention_delta(o, dout, delta_ws, B, T, H, hd, ldo, ldo, dtype, st));
+    // dO shares O's row stride.  The MFMA dQ kernel computes delta itself (and leaves it in delta_ws for the dK/dV kernel)
     if (impl == 0 && dtype == AV_BF16 && (hd == 128 || hd == 64))
-        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st, G);
+        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st, G, o, ldo);
+    AV_TRY(av_attention_delta(o, dout, delta_ws, B, T, H, hd, ldo, ldo, dtype, st));
     return av_attention_bwd_ref(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, st, G);
 }

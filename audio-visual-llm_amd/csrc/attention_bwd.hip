@@ -64,9 +64,9 @@ __device__ __forceinline__ void store_rows(const RowRegs<HD, NT, ROWS>& r, char*
 template <int HD, int NW, bool CAUSAL>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                             const bf16* __restrict__ v, const bf16* __restrict__ dout,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            const float* __restrict__ lse, float* __restrict__ delta,
                                                             bf16* __restrict__ dq, int T, int H, long ldq, long ldk, long ldv,
-                                                            long lddo, long lddq, float scale, int G) {
+                                                            long lddo, long lddq, float scale, int G, const bf16* __restrict__ o, long ldo) {
     constexpr int RS = HD * 2 + 16, TS = HD * 2 + 64, NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char k_row[64 * RS];
     __shared__ __attribute__((aligned(16))) char k_tr[64 * TS];
@@ -87,7 +87,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_mfma(const bf16* __res
         for (int ks = 0; ks < HD / 16; ++ks) { qf[ks] = *(const bf16x8*)(qp + 16 * ks); dof[ks] = *(const bf16x8*)(dp + 16 * ks); }
     }
     const float lse2 = lse[((long)b * H + hh) * T + qrow] * 1.4426950408889634f;
-    const float dlt = delta[((long)b * H + hh) * T + qrow];
+    // delta = rowsum(dO * O): this kernel already holds its query's dO row (half of it per lane), so it computes delta itself and
+    // publishes it for the dK/dV kernel that follows on the stream (one launch and one pass over O and dO fewer per layer)
+    float dlt = 0.f;
+    {
+        const bf16* orow = o + ((long)b * T + qrow) * ldo + (long)hh * HD + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            const bf16x8 of = *(const bf16x8*)(orow + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt += (float)dof[ks][j] * (float)of[j];
+        }
+        dlt += __shfl_xor(dlt, 32);
+        if (half == 0 && qpos < T) delta[((long)b * H + hh) * T + qpos] = dlt;
+    }
     f32x16 acc[HD / 32];
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d)
@@ -276,16 +289,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
 }
 
 template <int HD>
-int launch_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, void* dq,
+int launch_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta, void* dq,
                void* dk, void* dv, int B, int T, int H, long ldq, long ldk, long ldv, long lddo, long lddq, long lddk, long lddv,
-               float scale, int causal, hipStream_t st, int G) {
+               float scale, int causal, hipStream_t st, int G, const void* o, long ldo) {
     constexpr int NW = 4;
     const dim3 grid(av_cdiv(T, 32 * NW), H, B), gridkv(av_cdiv(T, 32 * NW), H / G, B), block(NW * 64);
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, (float*)delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G, (const bf16*)o, ldo);
         hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, true>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, (float*)delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G, (const bf16*)o, ldo);
         hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, false>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G);
     }
     AV_LAUNCH_CHECK();
@@ -294,10 +307,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* dout, co
 
 }  // namespace
 
-int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G) {
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G, const void* o, long ldo) {
     AV_CHECK_ARG(hd == 128 || hd == 64, "attention_bwd(mfma): head_dim %d unsupported", hd);
-    if (hd == 128) return launch_bwd<128>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G);
-    return launch_bwd<64>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G);
+    if (hd == 128) return launch_bwd<128>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G, o, ldo);
+    return launch_bwd<64>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G, o, ldo);
 }
