@@ -22,7 +22,7 @@ int av_attention_bwd_ref(const void* q, const void* k, const void* v, const void
                          long lddq, long lddk, long lddv, float scale, int causal, int dtype, hipStream_t st, int G);
 int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G, const void* o, long ldo);
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G, const void* o, long ldo, const float* rope_tab);
 
 namespace {
 
@@ -281,17 +281,20 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
     return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
 }
 
+bool av_attention_bwd_fuses_rope(int dtype, int hd, int impl) { return impl == 0 && dtype == AV_BF16 && (hd == 128 || hd == 64); }
+
 int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      void* dq, void* dk, void* dv, float* delta_ws, int B, int T, int H, int hd, long ldq, long ldk,
                      long ldv, long ldo, long lddq, long lddk, long lddv, float scale, int causal, int dtype, int impl,
-                     hipStream_t st, int kv_heads) {
+                     hipStream_t st, int kv_heads, const float* rope_tab) {
     AV_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta_ws, "attention_bwd: null");
+    AV_CHECK_ARG(!rope_tab || av_attention_bwd_fuses_rope(dtype, hd, impl), "attention_bwd: the fused inverse RoPE exists in the bf16 MFMA kernels only");
     if (kv_heads <= 0) kv_heads = H;
     AV_CHECK_ARG(H % kv_heads == 0, "attention_bwd: %d query heads are not a multiple of %d key/value heads", H, kv_heads);
     const int G = H / kv_heads;
     // dO shares O's row stride.  The MFMA dQ kernel computes delta itself (and leaves it in delta_ws for the dK/dV kernel)
     if (impl == 0 && dtype == AV_BF16 && (hd == 128 || hd == 64))
-        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st, G, o, ldo);
+        return av_attention_bwd_mfma(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, st, G, o, ldo, rope_tab);
     AV_TRY(av_attention_delta(o, dout, delta_ws, B, T, H, hd, ldo, ldo, dtype, st));
     return av_attention_bwd_ref(q, k, v, dout, lse, delta_ws, dq, dk, dv, B, T, H, hd, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, dtype, st, G);
 }

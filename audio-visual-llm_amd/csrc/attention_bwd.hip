@@ -60,13 +60,37 @@ __device__ __forceinline__ void store_rows(const RowRegs<HD, NT, ROWS>& r, char*
     }
 }
 
+// Inverse rotary embedding on a gradient row held in the MFMA output layout (lane = row, registers [d][4*g4+i] = element
+// 32d + 8g4 + 4half + i): element e < HD/2 pairs with e + HD/2, which the same lane holds in block d + HD/64.  table row t =
+// (cos, sin) interleaved per frequency (elementwise.hip rope_table_kernel).  Saves the separate pass over dq|dk after the kernel.
+template <int HD>
+__device__ __forceinline__ void unrope(f32x16 (&acc)[HD / 32], const float* __restrict__ tab, int t, int half) {
+    constexpr int HB = HD / 64;                                  // 32-wide blocks per half
+    const float* row = tab + (long)t * (HD / 2) * 2;
+#pragma unroll
+    for (int d = 0; d < HB; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int e = 32 * d + 8 * g4 + 4 * half;
+            const f32x4 c0 = *(const f32x4*)(row + 2 * e), c1 = *(const f32x4*)(row + 2 * e + 4);
+            const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = acc[d][4 * g4 + i], b = acc[d + HB][4 * g4 + i], c = cs[2 * i], sn = cs[2 * i + 1];
+                acc[d][4 * g4 + i] = a * c + b * sn;
+                acc[d + HB][4 * g4 + i] = b * c - a * sn;
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ dQ
 template <int HD, int NW, bool CAUSAL>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                             const bf16* __restrict__ v, const bf16* __restrict__ dout,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
                                                             bf16* __restrict__ dq, int T, int H, long ldq, long ldk, long ldv,
-                                                            long lddo, long lddq, float scale, int G, const bf16* __restrict__ o, long ldo) {
+                                                            long lddo, long lddq, float scale, int G, const bf16* __restrict__ o, long ldo,
+                                                            const float* __restrict__ rope_tab) {
     constexpr int RS = HD * 2 + 16, TS = HD * 2 + 64, NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char k_row[64 * RS];
     __shared__ __attribute__((aligned(16))) char k_tr[64 * TS];
@@ -161,6 +185,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_mfma(const bf16* __res
         }
     }
     if (!wave_active || qpos >= T) return;
+    if (rope_tab) unrope<HD>(acc, rope_tab, qpos, half);          // gradient w.r.t. the pre-RoPE q (transpose of the rotation)
     bf16* op = dq + ((long)b * T + qpos) * lddq + (long)hh * HD;
 #pragma unroll
     for (int d = 0; d < HD / 32; ++d)
@@ -177,7 +202,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
                                                              const bf16* __restrict__ v, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int T, int H, long ldq,
-                                                             long ldk, long ldv, long lddo, long lddk, long lddv, float scale, int G) {
+                                                             long ldk, long ldv, long lddo, long lddk, long lddv, float scale, int G,
+                                                             const float* __restrict__ rope_tab) {
     constexpr int RS = HD * 2 + 16, TS = HD * 2 + 64, NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char q_row[32 * RS];
     __shared__ __attribute__((aligned(16))) char q_tr[32 * TS];
@@ -275,6 +301,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
         }
     }
     if (!wave_active || kpos >= T) return;
+    if (rope_tab) unrope<HD>(dka, rope_tab, kpos, half);
     bf16* okp = dk + ((long)b * T + kpos) * lddk + (long)hh * HD;
     bf16* ovp = dv + ((long)b * T + kpos) * lddv + (long)hh * HD;
 #pragma unroll
@@ -291,15 +318,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
 template <int HD>
 int launch_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta, void* dq,
                void* dk, void* dv, int B, int T, int H, long ldq, long ldk, long ldv, long lddo, long lddq, long lddk, long lddv,
-               float scale, int causal, hipStream_t st, int G, const void* o, long ldo) {
+               float scale, int causal, hipStream_t st, int G, const void* o, long ldo, const float* rope_tab) {
     constexpr int NW = 4;
     const dim3 grid(av_cdiv(T, 32 * NW), H, B), gridkv(av_cdiv(T, 32 * NW), H / G, B), block(NW * 64);
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, (float*)delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G, (const bf16*)o, ldo);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, true>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, true>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, (float*)delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G, (const bf16*)o, ldo, rope_tab);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, true>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G, rope_tab);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, (float*)delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G, (const bf16*)o, ldo);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, false>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<HD, NW, false>), grid, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, (float*)delta, (bf16*)dq, T, H, ldq, ldk, ldv, lddo, lddq, scale, G, (const bf16*)o, ldo, rope_tab);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<HD, NW, false>), gridkv, block, 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, (bf16*)dk, (bf16*)dv, T, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, G, rope_tab);
     }
     AV_LAUNCH_CHECK();
     return AV_OK;
@@ -309,8 +336,9 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* dout, co
 
 int av_attention_bwd_mfma(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, int B, int T, int H, int hd, long ldq, long ldk, long ldv, long lddo,
-                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G, const void* o, long ldo) {
+                          long lddq, long lddk, long lddv, float scale, int causal, hipStream_t st, int G, const void* o, long ldo,
+                          const float* rope_tab) {
     AV_CHECK_ARG(hd == 128 || hd == 64, "attention_bwd(mfma): head_dim %d unsupported", hd);
-    if (hd == 128) return launch_bwd<128>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G, o, ldo);
-    return launch_bwd<64>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G, o, ldo);
+    if (hd == 128) return launch_bwd<128>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G, o, ldo, rope_tab);
+    return launch_bwd<64>(q, k, v, dout, lse, delta, dq, dk, dv, B, T, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, causal, st, G, o, ldo, rope_tab);
 }

@@ -19,7 +19,9 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
 int av_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      void* dq, void* dk, void* dv, float* delta_ws, int B, int T, int H, int hd, long ldq, long ldk,
                      long ldv, long ldo, long lddq, long lddk, long lddv, float scale, int causal, int dtype, int impl,
-                     hipStream_t st, int kv_heads = 0);
+                     hipStream_t st, int kv_heads = 0, const float* rope_tab = nullptr);
+// rope_tab != NULL: dq and dk come out as gradients w.r.t. the PRE-RoPE q/k (inverse rotation applied in the kernels' epilogues)
+bool av_attention_bwd_fuses_rope(int dtype, int hd, int impl);
 int av_ce_fwd(const void* logits, long ld, const int64_t* labels, int B, int T, int V, float* row_lse, float* loss_sum,
               float* count, int dtype, hipStream_t st);
 int av_ce_bwd(const void* logits, long ld, const int64_t* labels, const float* row_lse, const float* count,

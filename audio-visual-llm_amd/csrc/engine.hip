@@ -392,10 +392,11 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
         // ---- attention
         const char* qkv = (const char*)a.qkv;
         char* dqkv = (char*)w.dqkv;
+        const bool fuse_rope = av_attention_bwd_fuses_rope(dt, hd, 0);      // bf16: the inverse RoPE rides in the dq/dk epilogues
         AV_TRY(av_attention_bwd(qkv, qkv + (size_t)d * es, qkv + (size_t)(d + dkv) * es, a.att, w.datt, a.lse, dqkv, dqkv + (size_t)d * es,
                                 dqkv + (size_t)(d + dkv) * es, w.delta, B, S, H, hd, qw, qw, qw, d, qw, qw, qw,
-                                1.0f / sqrtf((float)hd), 1, dt, 0, st, Hkv));
-        AV_TRY(av_rope_tab(dqkv, qw, M, S, H + Hkv, hd, w.rope_tab, 1, dt, st));
+                                1.0f / sqrtf((float)hd), 1, dt, 0, st, Hkv, fuse_rope ? w.rope_tab : nullptr));
+        if (!fuse_rope) AV_TRY(av_rope_tab(dqkv, qw, M, S, H + Hkv, hd, w.rope_tab, 1, dt, st));
         // ---- q,k,v projections (+LoRA)
         bool any = false, contiguous = true;
         for (int j = 0; j < 3; ++j) {
