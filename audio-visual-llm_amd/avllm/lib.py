@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavllm.so")
+LIB_PATH = os.environ.get("AVLLM_LIB_PATH") or os.path.join(_HERE, "libavllm.so")      # override: A/B runs of two builds (tools/)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3

@@ -18,6 +18,8 @@
 #include "common.h"
 #include "avllm_internal.h"
 #include <stdlib.h>
+#include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -429,6 +431,175 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16, 256x256 tile, 4 waves x (128x128)
+// One wave per SIMD, each owning a 128x128 quadrant: 0.25 ds_read_b128 per MFMA instead of the 0.5 of a 64x64 wave tile
+// (at 16 waves the LDS port, reads + DMA writes, is busier than the MFMA pipe).  A K-step is 64 wide = 128 MFMAs per wave; the
+// fragments of BOTH k-halves of both operands sit in registers (128 VGPRs, accumulators in the 256 AGPRs), so an operand's half
+// of the current LDS buffer is dead after 8 ds_reads per wave and is refilled IN PLACE by the global->LDS DMA with the data of
+// K-step t+2: two 64-KiB buffers give two K-steps of load latency cover.  The loop is written instruction by instruction (the
+// compiler's own schedule for a single-wave-per-SIMD loop moved accumulators between AGPRs and VGPRs every iteration): three
+// barriers and three full lgkmcnt waits per 128 MFMAs, every ds_read issued >= 10 MFMAs before its wait, loads one per 2-3
+// MFMAs with SGPR base + 32-bit tile-relative VGPR offsets (no 64-bit address arithmetic, no operand-size limit).
+// tools/ubench/gemm_pingpong.hip g4h: 1.25-1.40 PF/s at 4096x4096x11008 against 1.15-1.17 for the 16-wave kernel in the same run.
+template <int N, int BUF>
+__device__ __forceinline__ void wgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2][2], const int (&lb)[2][2],
+                                           const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
+    constexpr int h = N >> 6, n = N & 63, I = n >> 3, J = n & 7;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
+#define AV_W_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(base) : "memory")
+    if constexpr (h == 0) {
+        if constexpr (n < 16 && (n & 1)) AV_W_RD(FB[1][n >> 1], lb[BUF][1], (n >> 1) * 2048);
+        if constexpr (n == 20) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (n == 21) __builtin_amdgcn_s_barrier();                          // every wave has read all of B(cur)
+        if constexpr (n >= 22 && n < 38 && !(n & 1)) AV_W_LD(vB[(n - 22) >> 1], pB, m0B + ((n - 22) >> 1) * 1024);
+        if constexpr (n >= 23 && n < 39 && (n & 1)) AV_W_RD(FA[1][(n - 23) >> 1], la[BUF][1], ((n - 23) >> 1) * 2048);
+        if constexpr (n == 50) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (n == 51) __builtin_amdgcn_s_barrier();                          // ... and all of A(cur)
+        if constexpr (n == 52 || n == 55 || n == 58 || n == 61) AV_W_LD(vA[(n - 52) / 3], pA, m0A + ((n - 52) / 3) * 1024);
+    } else {
+        if constexpr (n == 0) AV_W_LD(vA[4], pA, m0A + 4 * 1024);
+        if constexpr (n == 26) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // 13 loads of this step issued so far: all older ones have landed
+        if constexpr (n == 27) __builtin_amdgcn_s_barrier();                          // the other buffer is complete for every wave
+        if constexpr (n >= 28 && n < 36) AV_W_RD(FB[0][n - 28], lb[BUF ^ 1][0], (n - 28) * 2048);
+        if constexpr (n >= 37 && n < 53 && (n & 1)) AV_W_RD(FA[0][(n - 37) >> 1], la[BUF ^ 1][0], ((n - 37) >> 1) * 2048);
+        if constexpr (n == 32 || n == 40 || n == 48) AV_W_LD(vA[5 + (n - 32) / 8], pA, m0A + (5 + (n - 32) / 8) * 1024);
+        if constexpr (n == 62) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int BUF, int... Ns>
+__device__ __forceinline__ void wgemm_kstep(std::integer_sequence<int, Ns...>, f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2][2],
+                                            const int (&lb)[2][2], const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
+    (wgemm_step<Ns, BUF>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tiles_m = (g.e.M + HBM_ - 1) / HBM_, tiles_n = (g.e.N + HBN_ - 1) / HBN_;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * HBM_, n0 = tn * HBN_;
+    const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;                  // >= 2 (dispatcher)
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS: buffer b at b*64 KiB = A rows 0..255 then B rows 0..255, 128 B per row, 16-byte chunk index ^ (row & 7)
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int la[2][2], lb[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pc = ((4 * h + fq) ^ (fr & 7)) << 4;
+            la[b][h] = lds0 + b * HSTAGE + (wr * 128 + fr) * 128 + pc;
+            lb[b][h] = lds0 + b * HSTAGE + HBM_ * 128 + (wc * 128 + fr) * 128 + pc;
+        }
+    // Staging: one load = 8 rows x 128 B; this wave owns rows wave*64 + q*8 + (lane >> 3) of each operand.  Byte offsets relative to the
+    // tile's first row, per K segment (rows past the edge are clamped: they are never stored)
+    unsigned vA1[8], vB1[8], vA2[8], vB2[8];
+    const int ch = ((lane & 7) ^ (lane >> 3)) << 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = wave * 64 + q * 8 + (lane >> 3);
+        const unsigned ra = m0 + r < g.e.M ? r : g.e.M - 1 - m0, rb = n0 + r < g.e.N ? r : g.e.N - 1 - n0;
+        vA1[q] = ra * (unsigned)g.lda * 2 + ch; vA2[q] = ra * (unsigned)g.lda2 * 2 + ch;
+        vB1[q] = rb * (unsigned)g.ldb * 2 + ch; vB2[q] = rb * (unsigned)g.ldb2 * 2 + ch;
+    }
+    const bf16* tA1 = g.A + (long)m0 * g.lda; const bf16* tB1 = g.B + (long)n0 * g.ldb;
+    const bf16* tA2 = g.K2 ? g.A2 + (long)m0 * g.lda2 : g.A; const bf16* tB2 = g.K2 ? g.B2 + (long)n0 * g.ldb2 : g.B;
+    const int mw = lds0 + wave * 8192;                              // this wave's 64 rows inside an operand region
+    auto stage = [&](int kt, int buf) {
+        const bool s2 = kt >= nt1;
+        const bf16* pa = s2 ? tA2 + (long)(kt - nt1) * BK : tA1 + (long)kt * BK;
+        const bf16* pb = s2 ? tB2 + (long)(kt - nt1) * BK : tB1 + (long)kt * BK;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            AV_W_LD(s2 ? vA2[q] : vA1[q], pa, mw + buf * HSTAGE + q * 1024);
+            AV_W_LD(s2 ? vB2[q] : vB1[q], pb, mw + buf * HSTAGE + HBM_ * 128 + q * 1024);
+        }
+    };
+    bf16x8 FA[2][8], FB[2][8];
+    stage(0, 0); stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { AV_W_RD(FB[0][j], lb[0][0], 0); lb[0][0] += 2048; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { AV_W_RD(FA[0][i], la[0][0], 0); la[0][0] += 2048; }
+    lb[0][0] -= 8 * 2048; la[0][0] -= 8 * 2048;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    using Seq = std::make_integer_sequence<int, 128>;
+    // K-step t (buffer t & 1) issues the loads of K-step t+2 into its own buffer; past the end the last K-tile is loaded again into a
+    // buffer nobody reads any more, which keeps the vmcnt arithmetic of the loop uniform
+    auto kstep = [&](int t, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const int kl = t + 2 < nt ? t + 2 : nt - 1;
+        const bool s2 = kl >= nt1;
+        const bf16* pa = s2 ? tA2 + (long)(kl - nt1) * BK : tA1 + (long)kl * BK;
+        const bf16* pb = s2 ? tB2 + (long)(kl - nt1) * BK : tB1 + (long)kl * BK;
+        unsigned va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { va[q] = s2 ? vA2[q] : vA1[q]; vb[q] = s2 ? vB2[q] : vB1[q]; }
+        wgemm_kstep<BUF>(Seq{}, acc, FA, FB, la, lb, va, vb, pa, pb, mw + BUF * HSTAGE, mw + BUF * HSTAGE + HBM_ * 128);
+    };
+    int t = 0;
+    for (; t + 1 < nt; t += 2) { kstep(t, std::integral_constant<int, 0>{}); kstep(t + 1, std::integral_constant<int, 1>{}); }
+    if (t < nt) kstep(t, std::integral_constant<int, 0>{});
+    // the DMA writes of the dummy loads must have landed before LDS is reused; the nops cover the last MFMAs' result latency, which
+    // the compiler's hazard recogniser cannot see through inline asm
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __syncthreads();
+#undef AV_W_RD
+#undef AV_W_LD
+    if (g.wide_epi) {
+        // Epilogue through LDS, as in the 16-wave kernel: each 128-row half goes to LDS as fp32 and comes back as whole 16-byte row chunks
+        constexpr int CT_LD = 256;
+        float* ct = (float*)smem;                                    // [128][256] fp32 = both stage buffers
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wr == half) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = i * 16 + fr;
+                        *(f32x4*)(ct + row * CT_LD + (((wc * 32 + j * 4 + fq) ^ (row & 7)) << 2)) = acc[i][j];
+                    }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int p = 0; p < 16; ++p) {
+                const int idx = p * 256 + tid, row = idx >> 5, c8 = idx & 31;
+                const int m = m0 + half * 128 + row, n = n0 + c8 * 8;
+                if (m < g.e.M && n < g.e.N) {
+                    const f32x4 lo = *(const f32x4*)(ct + row * CT_LD + (((2 * c8) ^ (row & 7)) << 2));
+                    const f32x4 hi = *(const f32x4*)(ct + row * CT_LD + (((2 * c8 + 1) ^ (row & 7)) << 2));
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    epilogue_store8(g.e, m, n, v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + fr;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 8; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store4<bf16>(g.e, m, n0 + wc * 128 + j * 16 + fq * 4, v);
+        }
+    }
+}
+
 // Persistent form of the 16-wave kernel (gemm_bf16_h_kernel): one workgroup per CU walks tiles id, id+G, id+2G, ... and issues the FIRST K-tile of its
 // next output tile during the LAST K-step of the current one, so the per-tile prologue latency (exposed above, because a
 // 128 KiB workgroup has no co-resident partner) hides under compute and the epilogue stores overlap the next tile's loads.
@@ -711,7 +882,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
 
 }  // namespace
 
-static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent
+static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave
 extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
 void av_prof_before(hipStream_t st);
@@ -780,9 +951,13 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         // the 16-wave kernel keeps 32-bit element offsets of its staging rows: operands must stay below 2^32 elements
         const bool fits32 = (double)d->M * (double)(d->lda > d->lda2 ? d->lda : d->lda2) < 4.0e9 &&
                             (double)d->N * (double)(d->ldb > d->ldb2 ? d->ldb : d->ldb2) < 4.0e9;
-        const bool auto_h = variant == 0 && xtiles >= 200 && fits32;
+        const bool auto_h = variant == 0 && xtiles >= 200 && fits32;   // long K: 4-wave kernel, else 16-wave (tools/gemm_bench.py)
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
-        if (d->M > 128 && (variant == 5 || variant == 6 || auto_h)) {
+        if (d->M > 128 && (variant == 7 || (auto_h && d->K + d->K2 >= 4096)) && d->K + d->K2 >= 128) {
+            static bool attr7 = false;
+            if (!attr7) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE)); attr7 = true; }
+            hipLaunchKernelGGL(gemm_bf16_w_kernel, dim3(xtiles), dim3(256), 2 * HSTAGE, st, g);
+        } else if (d->M > 128 && (variant == 5 || variant == 6 || auto_h)) {
             AV_CHECK_ARG(fits32 || variant == 6, "gemm: operand too large for the 256x256 kernel's 32-bit row offsets");
             static bool attr4 = false;
             if (!attr4) {

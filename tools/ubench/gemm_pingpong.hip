@@ -701,6 +701,125 @@ __global__ __launch_bounds__(256, 1) void g4b(const bf16* __restrict__ A, const 
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 4 waves x 128x128, BK = 64 per iteration, BOTH k-halves' fragments of both operands held in registers (128 VGPRs), two 64-KiB
+// LDS buffers refilled IN PLACE by global->LDS DMA as soon as every wave has read an operand's half of the current buffer
+// (data for iteration t+2).  Three barriers and three full lgkmcnt waits per 128 MFMAs, every ds_read issued >= 10 MFMAs
+// before its wait, no VALU in the loop (SGPR base + constant 32-bit VGPR offsets for the loads).
+// 128-B LDS rows, 16-B chunk ^ (row & 7).  FLAGS: ablations 2 no loads, 4 no barriers, 8 no ds_reads; 16 MFMA order with srcA fixed
+template <int N, int BUF, int FLAGS>
+__device__ __forceinline__ void g4h_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2][2], const int (&lb)[2][2],
+                                         const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
+    constexpr int h = N >> 6, n = N & 63, I = (FLAGS & 16) ? (n & 7) : (n >> 3), J = (FLAGS & 16) ? (n >> 3) : (n & 7);   // 16: srcA fixed over 8 MFMAs instead of srcB
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
+#define G4H_RD(dst, addr, off) do { if (!(FLAGS & 8)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off)); } while (0)
+#define G4H_LD(voff, base, m0v) do { if (!(FLAGS & 2)) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(base) : "memory"); } while (0)
+#define G4H_BAR() do { if (!(FLAGS & 4)) __builtin_amdgcn_s_barrier(); } while (0)
+    if constexpr (h == 0) {
+        if constexpr (n < 16 && (n & 1)) G4H_RD(FB[1][n >> 1], lb[BUF][1], (n >> 1) * 2048);
+        if constexpr (n == 20) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (n == 21) G4H_BAR();                                              // every wave has read all of B(cur)
+        if constexpr (n >= 22 && n < 38 && !(n & 1)) G4H_LD(vB[(n - 22) >> 1], pB, m0B + ((n - 22) >> 1) * 1024);
+        if constexpr (n >= 23 && n < 39 && (n & 1)) G4H_RD(FA[1][(n - 23) >> 1], la[BUF][1], ((n - 23) >> 1) * 2048);
+        if constexpr (n == 50) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (n == 51) G4H_BAR();                                              // ... and all of A(cur)
+        if constexpr (n == 52 || n == 55 || n == 58 || n == 61) G4H_LD(vA[(n - 52) / 3], pA, m0A + ((n - 52) / 3) * 1024);
+    } else {
+        if constexpr (n == 0) G4H_LD(vA[4], pA, m0A + 4 * 1024);
+        if constexpr (n == 26) { if (FLAGS & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+        if constexpr (n == 27) G4H_BAR();                                              // the other buffer (loads of the previous iteration) has landed
+        if constexpr (n >= 28 && n < 36) G4H_RD(FB[0][n - 28], lb[BUF ^ 1][0], (n - 28) * 2048);
+        if constexpr (n >= 37 && n < 53 && (n & 1)) G4H_RD(FA[0][(n - 37) >> 1], la[BUF ^ 1][0], ((n - 37) >> 1) * 2048);
+        if constexpr (n == 32 || n == 40 || n == 48) G4H_LD(vA[5 + (n - 32) / 8], pA, m0A + (5 + (n - 32) / 8) * 1024);
+        if constexpr (n == 62) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef G4H_RD
+#undef G4H_LD
+#undef G4H_BAR
+}
+
+template <int BUF, int FLAGS, int... Ns>
+__device__ __forceinline__ void g4h_iter(std::integer_sequence<int, Ns...>, f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2][2],
+                                         const int (&lb)[2][2], const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
+    (g4h_step<Ns, BUF, FLAGS>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void g4h(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tiles_m = M / TM;
+    const int m0 = (blockIdx.x % tiles_m) * TM, n0 = (blockIdx.x / tiles_m) * TN;
+    const int nt = K / 64;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int la[2][2], lb[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pc = ((4 * h + fq) ^ (fr & 7)) << 4;
+            la[b][h] = lds0 + b * 65536 + (wr * 128 + fr) * 128 + pc;
+            lb[b][h] = lds0 + b * 65536 + 32768 + (wc * 128 + fr) * 128 + pc;
+        }
+    unsigned vA[8], vB[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned r = wave * 64 + q * 8 + (lane >> 3), ch = (lane & 7) ^ (lane >> 3);
+        vA[q] = (r * (unsigned)K + ch * 8) * 2; vB[q] = vA[q];
+    }
+    const bf16* tA = A + (long)m0 * K; const bf16* tB = B + (long)n0 * K;
+    const int mw = lds0 + wave * 8192;                           // this wave's 64 rows of an operand region
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(mw + buf * 65536 + q * 1024), "v"(vA[q]), "s"(tA + (long)kt * 64) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(mw + buf * 65536 + 32768 + q * 1024), "v"(vB[q]), "s"(tB + (long)kt * 64) : "memory");
+        }
+    };
+    bf16x8 FA[2][8], FB[2][8];
+    stage(0, 0); stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[0][j]) : "v"(lb[0][0]), "n"(0)); lb[0][0] += 2048;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FA[0][i]) : "v"(la[0][0]), "n"(0)); la[0][0] += 2048;
+    }
+    lb[0][0] -= 8 * 2048; la[0][0] -= 8 * 2048;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    using Seq = std::make_integer_sequence<int, 128>;
+    for (int t = 0; t < nt; t += 2) {
+        {
+            const int kl = t + 2 < nt ? t + 2 : nt - 1;          // past the end: the last tile again, into a buffer nobody reads any more
+            g4h_iter<0, FLAGS>(Seq{}, acc, FA, FB, la, lb, vA, vB, tA + (long)kl * 64, tB + (long)kl * 64, mw, mw + 32768);
+        }
+        {
+            const int kl = t + 3 < nt ? t + 3 : nt - 1;
+            g4h_iter<1, FLAGS>(Seq{}, acc, FA, FB, la, lb, vA, vB, tA + (long)kl * 64, tB + (long)kl * 64, mw + 65536, mw + 65536 + 32768);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = clock64() - ck0; g_clk[1] = wall_clock64() - wk0; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16* cp = C + (long)(m0 + wr * 128 + i * 16 + fr) * N + n0 + wc * 128 + j * 16 + fq * 4;
+            const f32x4 v = acc[i][j];
+            *(bf16x4*)cp = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+}
+
 // 16 waves, 64x64 per wave like the reference, but v_mfma_f32_32x32x16_bf16 (2x2 blocks): half the MFMA instructions and
 // operand register reads per flop.  128-B rows, chunk ^ ((row >> 1) & 7).
 __global__ __launch_bounds__(1024, 4) void g16m32(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C, int M, int N, int K) {
@@ -854,6 +973,33 @@ int main(int argc, char** argv) {
     float ms = timeit(gref<0>, 1024, A, B, C2, M, N, K, 20);
     { long long hk[2]; CK(hipMemcpyFromSymbol(hk, HIP_SYMBOL(g_clk), 16));
       printf("%-44s %8.1f us  %8.1f TF/s   main loop %.1f us, %.0f MHz\n", "reference (16 waves, 2 stages, syncthreads)", ms * 1000, fl / ms / 1e9, hk[1] / 100.0, 100.0 * hk[0] / hk[1]); }
+
+    if (argc > 4 && argv[4][0] == 'h') {
+        if ((K / 64) % 2) { printf("g4h needs K %% 128 == 0\n"); return 1; }
+        for (int v = 0; v < 6; ++v) {
+            CK(hipMemset(C, 0, (size_t)M * N * 2));
+            ms = v == 0 ? timeit(g4h<0>, 256, A, B, C, M, N, K, 20) : v == 1 ? timeit(g4h<16>, 256, A, B, C, M, N, K, 20) : v == 2 ? timeit(g4h<2>, 256, A, B, C, M, N, K, 20)
+               : v == 3 ? timeit(g4h<4>, 256, A, B, C, M, N, K, 20) : v == 4 ? timeit(g4h<8>, 256, A, B, C, M, N, K, 20) : timeit(gref<0>, 1024, A, B, C, M, N, K, 20);
+            unsigned short* hc = (unsigned short*)malloc((size_t)M * N * 2);
+            unsigned short* hr = (unsigned short*)malloc((size_t)M * N * 2);
+            CK(hipMemcpy(hc, C, (size_t)M * N * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr, C2, (size_t)M * N * 2, hipMemcpyDeviceToHost));
+            size_t bad = 0; double maxd = 0;
+            for (size_t i = 0; i < (size_t)M * N; ++i) {
+                unsigned int x = (unsigned int)hc[i] << 16, y = (unsigned int)hr[i] << 16;
+                float fx, fy; memcpy(&fx, &x, 4); memcpy(&fy, &y, 4);
+                const double d = fabs((double)fx - fy);
+                if (d > maxd) maxd = d;
+                if (d > 0.02 * fabs(fy) + 0.5) ++bad;
+            }
+            long long hk[2]; CK(hipMemcpyFromSymbol(hk, HIP_SYMBOL(g_clk), 16));
+            printf("%-44s %8.1f us  %8.1f TF/s   max|diff| %.3f  mismatches %zu  main loop %.1f us, %.0f MHz\n",
+                   v == 0 ? "4 waves, whole-k-half frags, in-place refill" : v == 1 ? "  same, MFMA order with srcA fixed" : v == 2 ? "  ablation: no global loads" : v == 3 ? "  ablation: no barriers" : v == 4 ? "  ablation: no ds_reads" : "reference again",
+                   ms * 1000, fl / ms / 1e9, maxd, bad, hk[1] / 100.0, hk[1] ? 100.0 * hk[0] / hk[1] : 0.0);
+            fflush(stdout);
+            free(hc); free(hr);
+        }
+        return 0;
+    }
 #define RUNM(MAPV, name) ms = timeit(gref<MAPV>, 1024, A, B, C, M, N, K, 20); { long long hk[2]; CK(hipMemcpyFromSymbol(hk, HIP_SYMBOL(g_clk), 16)); \
     printf("%-44s %8.1f us  %8.1f TF/s   main loop %.1f us, %.0f MHz\n", name, ms * 1000, fl / ms / 1e9, hk[1] / 100.0, 100.0 * hk[0] / hk[1]); }
     if ((M / 256) % 16 || (N / 256) % 16 || ((M / 256) * (N / 256)) % 8) { printf("tile grid not a multiple of 16x16: mapping variants skipped\n"); goto after_maps; }
