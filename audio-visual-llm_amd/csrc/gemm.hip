@@ -552,9 +552,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
     int t = 0;
     for (; t + 1 < nt; t += 2) { kstep(t, std::integral_constant<int, 0>{}); kstep(t + 1, std::integral_constant<int, 1>{}); }
     if (t < nt) kstep(t, std::integral_constant<int, 0>{});
-    // the DMA writes of the dummy loads must have landed before LDS is reused; the nops cover the last MFMAs' result latency, which
-    // the compiler's hazard recogniser cannot see through inline asm
+    // The DMA writes of the dummy loads must have landed before LDS is reused.  The nops cover the result latency of the last MFMAs, which
+    // the compiler's hazard recogniser cannot see through inline asm; naming every accumulator as an in/out operand of these statements
+    // keeps compiler-generated readers (register copies, spill stores) behind them -- without that hipcc placed a scratch store of the
+    // last accumulator directly after its MFMA and spilled a stale value.
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#define AV_W_PIN8(I) asm volatile("" : "+a"(acc[I][0]), "+a"(acc[I][1]), "+a"(acc[I][2]), "+a"(acc[I][3]), "+a"(acc[I][4]), "+a"(acc[I][5]), "+a"(acc[I][6]), "+a"(acc[I][7]))
+    AV_W_PIN8(0); AV_W_PIN8(1); AV_W_PIN8(2); AV_W_PIN8(3); AV_W_PIN8(4); AV_W_PIN8(5); AV_W_PIN8(6); AV_W_PIN8(7);
+#undef AV_W_PIN8
     __syncthreads();
 #undef AV_W_RD
 #undef AV_W_LD

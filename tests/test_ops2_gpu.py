@@ -1,5 +1,7 @@
 """More op-level parity (GPU): special-cased GEMM paths and full-size shapes checked through size-independent
 properties (linearity) or against torch on the same device."""
+import math
+
 import pytest
 import torch
 
@@ -151,7 +153,7 @@ def test_attention_grouped_query(dev, dtype, impl, B, T, H, Hkv, hd):
         assert e < (3e-2 if dtype == torch.bfloat16 else 1e-5), (name, e)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 def test_every_gemm_tiling_agrees(dev, variant):
     """All bf16 tilings compiled into the library (A/B variants included) compute the same epilogue-fused GEMM."""
     from avllm import lib as L
@@ -167,6 +169,56 @@ def test_every_gemm_tiling_agrees(dev, variant):
     finally:
         lib.avllm_set_gemm_variant(0)
     close(out, ref, 0.3, 2e-2, f"gemm variant {variant}")
+
+
+@pytest.mark.parametrize("K,K2", [(128, 0), (192, 0), (64, 64), (448, 64), (1024, 128)])
+def test_gemm_4wave_kernel_ksteps_edges_epilogues(dev, K, K2):
+    """The 4-wave 256x256 kernel (in-place LDS refill, two K-steps of prefetch): even and odd K-step counts, the minimum of two, a LoRA
+    segment of one and two K-steps, M and N edges inside a tile, both epilogues, in-place residual, f32 output, row remap."""
+    from avllm import lib as L
+    lib = L.load()
+    try:
+        lib.avllm_set_gemm_variant(7)
+        for M, N in ((900, 520), (257, 516), (512, 256)):           # ragged edges / narrow epilogue (N % 8 != 0) / exact tiles
+            A, B = rnd(M, K, dtype=torch.bfloat16, seed=71), rnd(N, K, dtype=torch.bfloat16, seed=72)
+            A2 = rnd(M, K2, dtype=torch.bfloat16, seed=73) if K2 else None
+            B2 = rnd(N, K2, dtype=torch.bfloat16, seed=74) if K2 else None
+            bias, x = rnd(N, dtype=torch.bfloat16, seed=75), rnd(M, N, dtype=torch.bfloat16, seed=76)
+            acc = A.float() @ B.float().t() + (A2.float() @ B2.float().t() if K2 else 0.0)
+            out = x.clone()
+            ops.gemm(A, B, out=out, bias=bias, R=out, A2=A2, B2=B2, alpha=0.5)
+            close(out, 0.5 * acc + bias.float() + x.float(), 0.02 * math.sqrt(K + K2), 2e-2, f"4-wave in-place residual {M}x{N}x{K}+{K2}")
+            o32 = ops.gemm(A, B, bias=bias, A2=A2, B2=B2, out_f32=True, act=L.ACT_GELU)
+            close(o32, torch.nn.functional.gelu(acc + bias.float()), 0.01 * math.sqrt(K + K2), 1e-2, f"4-wave f32 gelu {M}x{N}x{K}+{K2}")
+        A, B = rnd(900, K, dtype=torch.bfloat16, seed=77), rnd(256, K, dtype=torch.bfloat16, seed=78)
+        pos = rnd(9, 256, dtype=torch.bfloat16, seed=79)
+        out = torch.zeros(1000, 256, device=dev, dtype=torch.bfloat16)
+        ops.gemm(A, B, out=out, R=pos, r_mod=9, remap=(9, 10, 1), M=900)
+        close(out.view(100, 10, 256)[:, 1:], (A.float() @ B.float().t()).view(100, 9, 256) + pos.float(), 0.02 * math.sqrt(K), 2e-2, "4-wave remap")
+        assert out.view(100, 10, 256)[:, 0].abs().max().item() == 0
+    finally:
+        lib.avllm_set_gemm_variant(0)
+
+
+def test_gemm_auto_dispatch_long_k_matches_16wave(dev):
+    """K >= 4096 with a chip-filling grid goes to the 4-wave kernel by itself; the 16-wave kernel must give the same numbers (same
+    MFMA, same K order inside a K-step; accumulation order across the two k-halves is identical too -> bit-equal bf16 outputs)."""
+    from avllm import lib as L
+    lib = L.load()
+    M, N, K, K2 = 4096, 4096, 4096, 64
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=81), rnd(N, K, dtype=torch.bfloat16, seed=82, scale=K ** -0.5)
+    A2, B2 = rnd(M, K2, dtype=torch.bfloat16, seed=83), rnd(N, K2, dtype=torch.bfloat16, seed=84, scale=0.1)
+    R = rnd(M, N, dtype=torch.bfloat16, seed=85)
+    auto = ops.gemm(A, B, R=R, A2=A2, B2=B2)
+    try:
+        lib.avllm_set_gemm_variant(5)
+        ref16 = ops.gemm(A, B, R=R, A2=A2, B2=B2)
+    finally:
+        lib.avllm_set_gemm_variant(0)
+    assert torch.equal(auto, ref16)
+    rows = torch.randperm(M, device=dev)[:64]
+    ref = A[rows].float() @ B.float().t() + A2[rows].float() @ B2.float().t() + R[rows].float()
+    close(auto[rows], ref, 0.05, 2e-2, "auto-dispatched long-K gemm")
 
 
 @pytest.mark.parametrize("M", [1, 2, 8, 16])
