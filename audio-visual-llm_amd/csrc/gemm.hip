@@ -100,6 +100,24 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n
     else store_f<8>((bf16*)e.C + orow * e.ldc + n0, v);
 }
 
+// Lean item of the LDS-staged epilogue for the common case (bf16 output, alpha = 1, no dropout, no row remap, plain residual, tile fully
+// inside the matrix): the general epilogue_store8 spends most of its instructions on 64-bit index arithmetic and on uniform branches
+// around features these calls do not use.  lo/hi = the two fp32 LDS chunks of this item, b = the thread's bias (zeros without one).
+template <int ACT>
+__device__ __forceinline__ void epilogue_fast8(const f32x4 lo, const f32x4 hi, const float (&b)[8], const bf16* rp, bf16* cp) {      // rp may alias cp (in-place residual)
+    float v[8] = {lo[0] + b[0], lo[1] + b[1], lo[2] + b[2], lo[3] + b[3], hi[0] + b[4], hi[1] + b[5], hi[2] + b[6], hi[3] + b[7]};
+    if constexpr (ACT != AV_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], ACT);
+    }
+    if (rp) {
+        const bf16x8 r = *(const bf16x8*)rp;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+    }
+    store_f<8>(cp, v);
+}
+
 // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
 // range of logical tile ids.  Bijective for any grid size (cdna guide §5, "XCD swizzle must be bijective").
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -392,6 +410,44 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
         // to LDS as fp32 and comes back as whole 16-byte row chunks: bias/residual loads and the stores are row-coalesced.
         constexpr int CT_LD = 256;                           // floats per LDS row; 16-byte chunk index XOR (row & 7) instead of padding
         float* ct = (float*)smem;                            // [128][256] fp32 = 131,072 B = 2 * HSTAGE exactly
+        if (g.e.alpha == 1.f && g.e.drop_p <= 0.f && g.e.g_in <= 0 && !g.e.out_f32 && g.e.r_mod <= 0 && m0 + HBM_ <= g.e.M && n0 + HBN_ <= g.e.N) {
+            // thread = one 8-column chunk (tid & 31) of rows (tid >> 5) + 32 p: its bias, its LDS chunk pair and its row strides are fixed
+            const int ch = tid & 31, prow = tid >> 5;
+            float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (g.e.bias) load_f<8>((const bf16*)g.e.bias + n0 + ch * 8, b);
+            const float* clo = ct + prow * CT_LD + (((2 * ch) ^ (prow & 7)) << 2);
+            const float* chi = ct + prow * CT_LD + (((2 * ch + 1) ^ (prow & 7)) << 2);
+            bf16* cp = (bf16*)g.e.C + (long)(m0 + prow) * g.e.ldc + n0 + ch * 8;
+            const bf16* rp = g.e.R ? (const bf16*)g.e.R + (long)(m0 + prow) * g.e.ldr + n0 + ch * 8 : nullptr;
+            const long cstep = 32 * g.e.ldc, rstep = g.e.R ? 32 * g.e.ldr : 0;
+            auto run = [&](auto actc) __attribute__((always_inline)) {
+                constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if ((wm >> 1) == half) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int row = (wm & 1) * 64 + i * 16 + fr;
+                                *(f32x4*)(ct + row * CT_LD + (((wn * 16 + j * 4 + fq) ^ (row & 7)) << 2)) = acc[i][j];
+                            }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        epilogue_fast8<ACT>(*(const f32x4*)(clo + p * 32 * CT_LD), *(const f32x4*)(chi + p * 32 * CT_LD), b, rp, cp);
+                        cp += cstep; rp += rstep;
+                    }
+                    __syncthreads();
+                }
+            };
+            if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
+            else if (g.e.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
+            else if (g.e.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
+            else run(std::integral_constant<int, AV_ACT_SILU>{});
+            return;
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if ((wm >> 1) == half) {
@@ -567,6 +623,44 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
         // Epilogue through LDS, as in the 16-wave kernel: each 128-row half goes to LDS as fp32 and comes back as whole 16-byte row chunks
         constexpr int CT_LD = 256;
         float* ct = (float*)smem;                                    // [128][256] fp32 = both stage buffers
+        if (g.e.alpha == 1.f && g.e.drop_p <= 0.f && g.e.g_in <= 0 && !g.e.out_f32 && g.e.r_mod <= 0 && m0 + HBM_ <= g.e.M && n0 + HBN_ <= g.e.N) {
+            // lean items (see the 16-wave kernel): thread = 8-column chunk (tid & 31) of rows (tid >> 5) + 8 p
+            const int ch = tid & 31, prow = tid >> 5;
+            float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (g.e.bias) load_f<8>((const bf16*)g.e.bias + n0 + ch * 8, b);
+            const float* clo = ct + prow * CT_LD + (((2 * ch) ^ prow) << 2);
+            const float* chi = ct + prow * CT_LD + (((2 * ch + 1) ^ prow) << 2);
+            bf16* cp = (bf16*)g.e.C + (long)(m0 + prow) * g.e.ldc + n0 + ch * 8;
+            const bf16* rp = g.e.R ? (const bf16*)g.e.R + (long)(m0 + prow) * g.e.ldr + n0 + ch * 8 : nullptr;
+            const long cstep = 8 * g.e.ldc, rstep = g.e.R ? 8 * g.e.ldr : 0;
+            auto run = [&](auto actc) __attribute__((always_inline)) {
+                constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (wr == half) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int row = i * 16 + fr;
+                                *(f32x4*)(ct + row * CT_LD + (((wc * 32 + j * 4 + fq) ^ (row & 7)) << 2)) = acc[i][j];
+                            }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        epilogue_fast8<ACT>(*(const f32x4*)(clo + p * 8 * CT_LD), *(const f32x4*)(chi + p * 8 * CT_LD), b, rp, cp);
+                        cp += cstep; rp += rstep;
+                    }
+                    __syncthreads();
+                }
+            };
+            if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
+            else if (g.e.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
+            else if (g.e.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
+            else run(std::integral_constant<int, AV_ACT_SILU>{});
+            return;
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (wr == half) {
@@ -956,9 +1050,10 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         // the 16-wave kernel keeps 32-bit element offsets of its staging rows: operands must stay below 2^32 elements
         const bool fits32 = (double)d->M * (double)(d->lda > d->lda2 ? d->lda : d->lda2) < 4.0e9 &&
                             (double)d->N * (double)(d->ldb > d->ldb2 ? d->ldb : d->ldb2) < 4.0e9;
-        const bool auto_h = variant == 0 && xtiles >= 200 && fits32;   // long K: 4-wave kernel, else 16-wave (tools/gemm_bench.py)
+        const bool auto_h = variant == 0 && xtiles >= 200 && fits32;   // 4-wave kernel for long K (fixed cost 10.9 us per tile + 1.43 us per K-step against
+        // 7.7 + 1.67 for the 16-wave kernel, tools/gemm_ktile_sweep.py; small grids favour the 16-wave kernel a little longer)
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
-        if (d->M > 128 && (variant == 7 || (auto_h && d->K + d->K2 >= 4096)) && d->K + d->K2 >= 128) {
+        if (d->M > 128 && (variant == 7 || (auto_h && (d->K + d->K2 >= 4096 || (d->K + d->K2 >= 2048 && xtiles >= 1024)))) && d->K + d->K2 >= 128) {
             static bool attr7 = false;
             if (!attr7) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE)); attr7 = true; }
             hipLaunchKernelGGL(gemm_bf16_w_kernel, dim3(xtiles), dim3(256), 2 * HSTAGE, st, g);

@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
         losses.append(float(tr.train_step(audio[sl].cuda(), video[sl].cuda(), labels[sl].cuda(), prompt[sl].cuda())))
     torch.cuda.synchronize()
     if rank == 0:
-        q.put((losses, m.llm_engine.lora_p.cpu()))
+        q.put((losses, m.llm_engine.lora_p.cpu().numpy()))      # by value: a tensor travels as an fd the parent may fetch after this process exits
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,6 +55,7 @@ def test_two_ranks_equal_one_process(dev):
     for p in procs:
         p.start()
     losses, params = q.get(timeout=600)
+    params = torch.from_numpy(params)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
