@@ -699,6 +699,198 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
     }
 }
 
+// Persistent form of the 4-wave kernel for calls the lean epilogue covers (bf16 output, alpha 1, no dropout / row remap / broadcast
+// residual).  One workgroup per CU walks tiles vid, vid+G, ...; the K-step pipeline never drains between them: the last two K-steps of a
+// tile issue the loads of the NEXT tile's first two K-steps (where the one-shot kernel issues dummy loads), so a tile's prologue latency
+// and the workgroup relaunch disappear behind the previous tile.  The epilogue therefore stays out of the two stage buffers: each wave
+// transposes its own 128x128 quadrant 16 rows at a time through a private 8-KiB slice of the remaining 32 KiB of LDS (same-wave LDS
+// traffic is in order: no workgroup barrier), and the accumulators are re-initialised for free by the first K-step's MFMAs taking 0 as
+// their C operand.  Buffers alternate by address arithmetic, so any K-step count and tile parity runs the same loop body.
+template <int N, bool FIRST>
+__device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2], const int (&lb)[2],
+                                            const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
+    constexpr int h = N >> 6, n = N & 63, I = n >> 3, J = n & 7;
+    if constexpr (FIRST && h == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
+#define AV_W_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(base) : "memory")
+    // la/lb[1]: this lane's k-half-1 fragment address in the CURRENT buffer; la/lb[0]: k-half 0 in the OTHER buffer (next K-step)
+    if constexpr (h == 0) {
+        if constexpr (n < 16 && (n & 1)) AV_W_RD(FB[1][n >> 1], lb[1], (n >> 1) * 2048);
+        if constexpr (n == 20) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (n == 21) __builtin_amdgcn_s_barrier();
+        if constexpr (n >= 22 && n < 38 && !(n & 1)) AV_W_LD(vB[(n - 22) >> 1], pB, m0B + ((n - 22) >> 1) * 1024);
+        if constexpr (n >= 23 && n < 39 && (n & 1)) AV_W_RD(FA[1][(n - 23) >> 1], la[1], ((n - 23) >> 1) * 2048);
+        if constexpr (n == 50) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (n == 51) __builtin_amdgcn_s_barrier();
+        if constexpr (n == 52 || n == 55 || n == 58 || n == 61) AV_W_LD(vA[(n - 52) / 3], pA, m0A + ((n - 52) / 3) * 1024);
+    } else {
+        if constexpr (n == 0) AV_W_LD(vA[4], pA, m0A + 4 * 1024);
+        if constexpr (n == 26) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        if constexpr (n == 27) __builtin_amdgcn_s_barrier();
+        if constexpr (n >= 28 && n < 36) AV_W_RD(FB[0][n - 28], lb[0], (n - 28) * 2048);
+        if constexpr (n >= 37 && n < 53 && (n & 1)) AV_W_RD(FA[0][(n - 37) >> 1], la[0], ((n - 37) >> 1) * 2048);
+        if constexpr (n == 32 || n == 40 || n == 48) AV_W_LD(vA[5 + (n - 32) / 8], pA, m0A + (5 + (n - 32) / 8) * 1024);
+        if constexpr (n == 62) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <bool FIRST, int... Ns>
+__device__ __forceinline__ void wpgemm_kstep(std::integer_sequence<int, Ns...>, f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2],
+                                             const int (&lb)[2], const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
+    (wpgemm_step<Ns, FIRST>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
+}
+
+constexpr int WP_LDS = 2 * HSTAGE + 4 * 8192;                       // two stage buffers + one 16x128 fp32 transpose slice per wave = 160 KiB
+
+template <bool HAS2>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int tiles_m = (g.e.M + HBM_ - 1) / HBM_, tiles_n = (g.e.N + HBN_ - 1) / HBN_;
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;             // G <= ntiles (dispatcher)
+    const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;                  // >= 2 (dispatcher)
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int pc0 = (fq ^ (fr & 7)) << 4, pc1 = ((4 + fq) ^ (fr & 7)) << 4;
+    const int rowA = lds0 + (wr * 128 + fr) * 128, rowB = lds0 + HBM_ * 128 + (wc * 128 + fr) * 128;
+    int la[2] = {rowA + HSTAGE + pc0, rowA + pc1}, lb[2] = {rowB + HSTAGE + pc0, rowB + pc1};     // current buffer = 0
+    int bo = 0;                                                      // byte offset of the current buffer
+    const int mw = lds0 + wave * 8192;
+    const unsigned ch = ((lane & 7) ^ (lane >> 3)) << 4, r0 = wave * 64 + (lane >> 3);
+
+    // Load context: the tile whose K-steps are being fetched (up to two K-steps ahead of the tile being multiplied).  Offsets as in the
+    // one-shot kernel; the second K segment's (LoRA: one K-step per tile) are rebuilt in the K-steps that need them.
+    unsigned vA1[8], vB1[8];
+    const bf16 *tA1, *tB1;
+    int lvid = blockIdx.x, lt = 0, lm0 = 0, ln0 = 0;
+    auto set_ctx = [&](int vid) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
+        lm0 = tm * HBM_; ln0 = tn * HBN_;
+        const unsigned la2 = (unsigned)g.lda * 2, lb2 = (unsigned)g.ldb * 2, ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned r = r0 + q * 8;
+            vA1[q] = __umul24(r < ma ? r : ma, la2) + ch; vB1[q] = __umul24(r < mb ? r : mb, lb2) + ch;
+        }
+        tA1 = g.A + (long)lm0 * g.lda; tB1 = g.B + (long)ln0 * g.ldb;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {            // after K-step lt of the context tile has been issued
+        if (++lt < nt) return;
+        if (lvid + G < ntiles) { lvid += G; set_ctx(lvid); lt = 0; }
+        else lt = nt - 1;                                            // nothing left: keep re-fetching the last K-step (never read); the loop's vmcnt arithmetic stays uniform
+    };
+    auto seg2_offsets = [&](unsigned (&va)[8], unsigned (&vb)[8], const bf16*& pa, const bf16*& pb) __attribute__((always_inline)) {
+        const unsigned la2 = (unsigned)g.lda2 * 2, lb2 = (unsigned)g.ldb2 * 2, ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned r = r0 + q * 8;
+            va[q] = __umul24(r < ma ? r : ma, la2) + ch; vb[q] = __umul24(r < mb ? r : mb, lb2) + ch;
+        }
+        pa = g.A2 + (long)lm0 * g.lda2 + (long)(lt - nt1) * BK; pb = g.B2 + (long)ln0 * g.ldb2 + (long)(lt - nt1) * BK;
+    };
+    set_ctx(lvid);
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        unsigned va[8], vb[8];
+        const bf16 *pa = tA1 + (long)lt * BK, *pb = tB1 + (long)lt * BK;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { va[q] = vA1[q]; vb[q] = vB1[q]; }
+        if constexpr (HAS2) { if (lt >= nt1) seg2_offsets(va, vb, pa, pb); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            AV_W_LD(va[q], pa, mw + s * HSTAGE + q * 1024);
+            AV_W_LD(vb[q], pb, mw + s * HSTAGE + HBM_ * 128 + q * 1024);
+        }
+        advance();
+    }
+    f32x4 acc[8][8];
+    bf16x8 FA[2][8], FB[2][8];
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        int a0 = rowA + pc0, b0 = rowB + pc0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { AV_W_RD(FB[0][j], b0, 0); b0 += 2048; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { AV_W_RD(FA[0][i], a0, 0); a0 += 2048; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    using Seq = std::make_integer_sequence<int, 128>;
+    auto kstep = [&](auto firstc) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(firstc)::value;
+        if constexpr (HAS2) {
+            unsigned va[8], vb[8];
+            const bf16 *pa = tA1 + (long)lt * BK, *pb = tB1 + (long)lt * BK;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { va[q] = vA1[q]; vb[q] = vB1[q]; }
+            if (lt >= nt1) seg2_offsets(va, vb, pa, pb);
+            wpgemm_kstep<FIRST>(Seq{}, acc, FA, FB, la, lb, va, vb, pa, pb, mw + bo, mw + bo + HBM_ * 128);
+        } else {
+            wpgemm_kstep<FIRST>(Seq{}, acc, FA, FB, la, lb, vA1, vB1, tA1 + (long)lt * BK, tB1 + (long)lt * BK, mw + bo, mw + bo + HBM_ * 128);
+        }
+        const int d = bo ? -HSTAGE : HSTAGE;
+        la[1] += d; lb[1] += d; la[0] -= d; lb[0] -= d; bo += d;
+        advance();
+    };
+    // epilogue geometry: item p of a 16-row block = row 4p + (lane >> 4), columns 8 (lane & 15) .. +7 of the wave's 128
+    float* cw = (float*)(smem + 2 * HSTAGE + wave * 8192);           // this wave's transpose slice: 16 rows x 128 fp32, 16-byte chunk ^ (row & 7)
+    const int c8 = lane & 15, prow = lane >> 4;
+    for (int vid = blockIdx.x; vid < ntiles; vid += G) {
+        kstep(std::true_type{});
+#pragma unroll 1
+        for (int t = 1; t < nt; ++t) kstep(std::false_type{});
+        // result latency of the last MFMAs (invisible to the compiler's hazard recogniser): nops, and every accumulator named as an in/out
+        // operand so that compiler-generated readers stay behind them
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#define AV_W_PIN8(I) asm volatile("" : "+a"(acc[I][0]), "+a"(acc[I][1]), "+a"(acc[I][2]), "+a"(acc[I][3]), "+a"(acc[I][4]), "+a"(acc[I][5]), "+a"(acc[I][6]), "+a"(acc[I][7]))
+        AV_W_PIN8(0); AV_W_PIN8(1); AV_W_PIN8(2); AV_W_PIN8(3); AV_W_PIN8(4); AV_W_PIN8(5); AV_W_PIN8(6); AV_W_PIN8(7);
+#undef AV_W_PIN8
+        int tm, tn;
+        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
+        const int m0 = tm * HBM_ + wr * 128, n = tn * HBN_ + wc * 128 + c8 * 8;
+        const bool ncol = n < g.e.N;
+        float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g.e.bias && ncol) load_f<8>((const bf16*)g.e.bias + n, b);
+        auto run = [&](auto actc) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(actc)::value;
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 8; ++i) {
+#pragma clang loop unroll(full)
+                for (int j = 0; j < 8; ++j) *(f32x4*)(cw + fr * 128 + (((j * 4 + fq) ^ (fr & 7)) << 2)) = acc[i][j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pins the compiler's ordering of the slice's writes and reads
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 4; ++p) {
+                    const int row = p * 4 + prow, m = m0 + i * 16 + row;
+                    const f32x4 lo = *(const f32x4*)(cw + row * 128 + (((2 * c8) ^ (row & 7)) << 2));
+                    const f32x4 hi = *(const f32x4*)(cw + row * 128 + (((2 * c8 + 1) ^ (row & 7)) << 2));
+                    if (ncol && m < g.e.M)
+                        epilogue_fast8<ACT>(lo, hi, b, g.e.R ? (const bf16*)g.e.R + (long)m * g.e.ldr + n : nullptr, (bf16*)g.e.C + (long)m * g.e.ldc + n);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
+        if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
+        else if (g.e.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
+        else if (g.e.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
+        else run(std::integral_constant<int, AV_ACT_SILU>{});
+        // The next tile's k-half-0 fragments are read again here (its first K-step is complete in the current buffer: the last K-step's
+        // barrier covered it) instead of being carried through the epilogue: 64 registers the epilogue code can use
+        if (vid + G < ntiles) {
+            int a0 = la[1] - pc1 + pc0, b0 = lb[1] - pc1 + pc0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { AV_W_RD(FB[0][j], b0, 0); b0 += 2048; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { AV_W_RD(FA[0][i], a0, 0); a0 += 2048; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // in-flight DMA writes must not outlive the workgroup's LDS allocation
+#undef AV_W_RD
+#undef AV_W_LD
+}
+
 // Persistent form of the 16-wave kernel (gemm_bf16_h_kernel): one workgroup per CU walks tiles id, id+G, id+2G, ... and issues the FIRST K-tile of its
 // next output tile during the LAST K-step of the current one, so the per-tile prologue latency (exposed above, because a
 // 128 KiB workgroup has no co-resident partner) hides under compute and the epilogue stores overlap the next tile's loads.
@@ -981,7 +1173,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
 
 }  // namespace
 
-static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave
+static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave, 8 256x256 4-wave persistent (lean epilogue only)
 extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
 void av_prof_before(hipStream_t st);
@@ -1053,7 +1245,19 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         const bool auto_h = variant == 0 && xtiles >= 200 && fits32;   // 4-wave kernel for long K (fixed cost 10.9 us per tile + 1.43 us per K-step against
         // 7.7 + 1.67 for the 16-wave kernel, tools/gemm_ktile_sweep.py; small grids favour the 16-wave kernel a little longer)
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
-        if (d->M > 128 && (variant == 7 || (auto_h && (d->K + d->K2 >= 4096 || (d->K + d->K2 >= 2048 && xtiles >= 1024)))) && d->K + d->K2 >= 128) {
+        const bool lean_ok = wide_ok && d->alpha == 1.f && d->drop_p <= 0.f && d->g_in <= 0 && !e.out_f32 && d->r_mod <= 0;
+        if (d->M > 128 && (variant == 8 || auto_h) && lean_ok && d->K + d->K2 >= 128) {
+            static bool attr8 = false;
+            if (!attr8) {
+                AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_wp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS));
+                AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_wp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS));
+                attr8 = true;
+            }
+            static int ncu8 = 0;
+            if (!ncu8) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu8, hipDeviceAttributeMultiprocessorCount, dev)); }
+            if (d->K2 > 0) hipLaunchKernelGGL(gemm_bf16_wp_kernel<true>, dim3(xtiles < ncu8 ? xtiles : ncu8), dim3(256), WP_LDS, st, g);
+            else hipLaunchKernelGGL(gemm_bf16_wp_kernel<false>, dim3(xtiles < ncu8 ? xtiles : ncu8), dim3(256), WP_LDS, st, g);
+        } else if (d->M > 128 && (variant == 7 || (auto_h && (d->K + d->K2 >= 4096 || (d->K + d->K2 >= 2048 && xtiles >= 1024)))) && d->K + d->K2 >= 128) {
             static bool attr7 = false;
             if (!attr7) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE)); attr7 = true; }
             hipLaunchKernelGGL(gemm_bf16_w_kernel, dim3(xtiles), dim3(256), 2 * HSTAGE, st, g);
