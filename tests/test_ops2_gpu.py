@@ -153,7 +153,7 @@ def test_attention_grouped_query(dev, dtype, impl, B, T, H, Hkv, hd):
         assert e < (3e-2 if dtype == torch.bfloat16 else 1e-5), (name, e)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7, 8])
 def test_every_gemm_tiling_agrees(dev, variant):
     """All bf16 tilings compiled into the library (A/B variants included) compute the same epilogue-fused GEMM."""
     from avllm import lib as L
@@ -219,6 +219,35 @@ def test_gemm_auto_dispatch_long_k_matches_16wave(dev):
     rows = torch.randperm(M, device=dev)[:64]
     ref = A[rows].float() @ B.float().t() + A2[rows].float() @ B2.float().t() + R[rows].float()
     close(auto[rows], ref, 0.05, 2e-2, "auto-dispatched long-K gemm")
+
+
+@pytest.mark.parametrize("K,K2,act", [(128, 0, "none"), (192, 64, "quick_gelu"), (320, 0, "gelu")])
+def test_gemm_persistent_kernel_many_tiles(dev, K, K2, act):
+    """The persistent 4-wave kernel with more tiles than CUs (each workgroup walks several tiles, the K-step pipeline runs across tile
+    boundaries, odd and even K-step counts so the buffer parity flips between tiles), ragged M / N edges, bias + in-place residual +
+    activation: bit-equal to the 16-wave kernel (same MFMA order, same single rounding) and within bf16 tolerance of fp32 torch."""
+    from avllm import lib as L
+    lib = L.load()
+    M, N = 4300, 4360                                              # 17 x 18 = 306 tiles on 256 CUs
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=91), rnd(N, K, dtype=torch.bfloat16, seed=92, scale=K ** -0.5)
+    A2 = rnd(M, K2, dtype=torch.bfloat16, seed=93) if K2 else None
+    B2 = rnd(N, K2, dtype=torch.bfloat16, seed=94, scale=0.1) if K2 else None
+    bias, x = rnd(N, dtype=torch.bfloat16, seed=95), rnd(M, N, dtype=torch.bfloat16, seed=96)
+    code = {"none": L.ACT_NONE, "gelu": L.ACT_GELU, "quick_gelu": L.ACT_QUICK_GELU}[act]
+    outs = {}
+    try:
+        for variant in (8, 5):
+            lib.avllm_set_gemm_variant(variant)
+            o = x.clone()
+            ops.gemm(A, B, out=o, bias=bias, R=o, A2=A2, B2=B2, act=code)
+            outs[variant] = o
+    finally:
+        lib.avllm_set_gemm_variant(0)
+    assert torch.equal(outs[8], outs[5])
+    rows = torch.cat([torch.randperm(M, device=dev)[:48], torch.tensor([0, 255, 256, M - 1], device=dev)])
+    acc = A[rows].float() @ B.float().t() + (A2[rows].float() @ B2.float().t() if K2 else 0.0) + bias.float()
+    fn = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
+    close(outs[8][rows], fn(acc) + x[rows].float(), 0.06, 2e-2, f"persistent gemm K={K}+{K2} {act}")
 
 
 @pytest.mark.parametrize("M", [1, 2, 8, 16])
