@@ -57,7 +57,7 @@ def pmc_traffic_bytes():
         n, b = 0, 0.0
         for line in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)):
             f = line.split()
-            if f and f[0] in ("gemm_bf16_h_kernel", "gemm_bf16_w_kernel"):       # the two 256x256 kernels: launch-weighted mean
+            if f and f[0] in ("gemm_bf16_wp_kernel", "gemm_bf16_h_kernel", "gemm_bf16_w_kernel"):       # the 256x256 kernels: launch-weighted mean
                 n += int(f[1]); b += int(f[1]) * (float(f[2]) + float(f[3])) * 2 ** 20
         return round(b / n) if n else None
     except OSError:
@@ -160,9 +160,9 @@ def main():
         frac_e2e = value / world * FLOP_PER_CLIP / MFMA_BF16_PEAK
         if timing and prof[2] > 0:
             ach = prof[1] / (prof[0] * 1e-3) / 1e12           # TFLOP/s over the GEMM launches only
-            out["roofline"] = {"bound": "mfma", "kernel": "avllm_gemm launches: every dense projection (256x256 tiles: gemm_bf16_w_kernel, 4 waves, for K >= 4096; gemm_bf16_h_kernel, 16 waves, otherwise)", "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "mfma", "kernel": "avllm_gemm launches: every dense projection (dominant: gemm_bf16_wp_kernel, persistent 256x256 tiles, 4 waves x 128x128)", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / (MFMA_BF16_PEAK / 1e12), 4),
-                               "traffic": pmc_traffic_bytes(), "traffic_note": "HBM bytes per 256x256-tile GEMM launch, launch-weighted over gemm_bf16_w_kernel and gemm_bf16_h_kernel (FETCH_SIZE x2-corrected + WRITE_SIZE) from the separate rocprofv3 --pmc passes summarised in " + PMC_SUMMARY,
+                               "traffic": pmc_traffic_bytes(), "traffic_note": "HBM bytes per 256x256-tile GEMM launch, launch-weighted over the 256x256 kernels (FETCH_SIZE x2-corrected + WRITE_SIZE) from the separate rocprofv3 --pmc passes summarised in " + PMC_SUMMARY,
                                "launches_per_step": int(prof[2] / args.steps),
                                "avg_launch_us": round(1000 * prof[0] / prof[2], 2), "gemm_ms_per_step": round(prof[0] / args.steps, 3),
                                "gemm_tflop_per_step": round(prof[1] / args.steps / 1e12, 3),

@@ -4,7 +4,7 @@ SQ_ACTIVE_INST_ANY pass: per kernel, MFMA-pipe busy cycles against (a) GRBM_GUI_
 definition -- and (b) wall time, plus the wave-cycle split.  Usage: pmc_mfma_summary.py <counter_collection.csv>"""
 import collections, csv, re, sys
 csv.field_size_limit(1 << 30)
-PAT = re.compile(r"(gemm_bf16_h_kernel|gemm_bf16_w_kernel|gemm_bf16_kernel|gemm_bf16_l_kernel|gemm_skinny64_kernel|gemm_tn_mfma_kernel|gemm_smallm_kernel|"
+PAT = re.compile(r"(gemm_bf16_wp_kernel<\w+>|gemm_bf16_h_kernel|gemm_bf16_w_kernel|gemm_bf16_kernel|gemm_bf16_l_kernel|gemm_skinny64_kernel|gemm_tn_mfma_kernel|gemm_smallm_kernel|"
                  r"attn_fwd_mfma<\d+, \d|attn_bwd_dkv_mfma|attn_bwd_dq_mfma)")
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 seen, dur, cnt = set(), collections.Counter(), collections.Counter()
