@@ -104,8 +104,12 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n
 // inside the matrix): the general epilogue_store8 spends most of its instructions on 64-bit index arithmetic and on uniform branches
 // around features these calls do not use.  lo/hi = the two fp32 LDS chunks of this item, b = the thread's bias (zeros without one).
 template <int ACT>
-__device__ __forceinline__ void epilogue_fast8(const f32x4 lo, const f32x4 hi, const float (&b)[8], const bf16* rp, bf16* cp) {      // rp may alias cp (in-place residual)
-    float v[8] = {lo[0] + b[0], lo[1] + b[1], lo[2] + b[2], lo[3] + b[3], hi[0] + b[4], hi[1] + b[5], hi[2] + b[6], hi[3] + b[7]};
+__device__ __forceinline__ void epilogue_fast8(const f32x4 lo, const f32x4 hi, const float (&b)[8], bool has_b, const bf16* rp, bf16* cp) {      // rp may alias cp (in-place residual)
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (has_b) {                                                   // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += b[i];
+    }
     if constexpr (ACT != AV_ACT_NONE) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], ACT);
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_h_kernel(GemmArgs g) {
                     __syncthreads();
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        epilogue_fast8<ACT>(*(const f32x4*)(clo + p * 32 * CT_LD), *(const f32x4*)(chi + p * 32 * CT_LD), b, rp, cp);
+                        epilogue_fast8<ACT>(*(const f32x4*)(clo + p * 32 * CT_LD), *(const f32x4*)(chi + p * 32 * CT_LD), b, g.e.bias != nullptr, rp, cp);
                         cp += cstep; rp += rstep;
                     }
                     __syncthreads();
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
                     __syncthreads();
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
-                        epilogue_fast8<ACT>(*(const f32x4*)(clo + p * 8 * CT_LD), *(const f32x4*)(chi + p * 8 * CT_LD), b, rp, cp);
+                        epilogue_fast8<ACT>(*(const f32x4*)(clo + p * 8 * CT_LD), *(const f32x4*)(chi + p * 8 * CT_LD), b, g.e.bias != nullptr, rp, cp);
                         cp += cstep; rp += rstep;
                     }
                     __syncthreads();
@@ -853,6 +857,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         const bool ncol = n < g.e.N;
         float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (g.e.bias && ncol) load_f<8>((const bf16*)g.e.bias + n, b);
+        // this lane's first row of the quadrant; item (i, p) is 16 i + 4 p rows further down: uniform (scalar) multiples of the row strides
+        bf16* const cp0 = (bf16*)g.e.C + (long)(m0 + prow) * g.e.ldc + n;
+        const bf16* const rp0 = g.e.R ? (const bf16*)g.e.R + (long)(m0 + prow) * g.e.ldr + n : nullptr;
+        const long ldc = g.e.ldc, ldr = g.e.R ? g.e.ldr : 0;
         auto run = [&](auto actc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(actc)::value;
 #pragma clang loop unroll(full)
@@ -865,8 +873,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
                     const int row = p * 4 + prow, m = m0 + i * 16 + row;
                     const f32x4 lo = *(const f32x4*)(cw + row * 128 + (((2 * c8) ^ (row & 7)) << 2));
                     const f32x4 hi = *(const f32x4*)(cw + row * 128 + (((2 * c8 + 1) ^ (row & 7)) << 2));
-                    if (ncol && m < g.e.M)
-                        epilogue_fast8<ACT>(lo, hi, b, g.e.R ? (const bf16*)g.e.R + (long)m * g.e.ldr + n : nullptr, (bf16*)g.e.C + (long)m * g.e.ldc + n);
+                    if (ncol && m < g.e.M) epilogue_fast8<ACT>(lo, hi, b, g.e.bias != nullptr, rp0 + (i * 16 + p * 4) * ldr, cp0 + (i * 16 + p * 4) * ldc);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
