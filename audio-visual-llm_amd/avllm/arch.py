@@ -79,7 +79,9 @@ class ModelCfg:
 
 WHISPER = {
     "tiny": WhisperCfg(384, 6, 4, 1536), "base": WhisperCfg(512, 8, 6, 2048), "small": WhisperCfg(768, 12, 12, 3072),
-    "medium": WhisperCfg(1024, 16, 24, 4096), "large": WhisperCfg(1280, 20, 32, 5120),
+    "medium": WhisperCfg(1024, 16, 24, 4096),
+    "large-v3": WhisperCfg(1280, 20, 32, 5120, n_mels=128),      # 128 mel bins (matched before "large"; BASELINE config 5)
+    "large": WhisperCfg(1280, 20, 32, 5120),
 }
 CLIP = {
     "base-patch16": ClipCfg(768, 12, 12, 3072, 224, 16), "base-patch32": ClipCfg(768, 12, 12, 3072, 224, 32),

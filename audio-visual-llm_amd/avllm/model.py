@@ -184,10 +184,11 @@ class ClipWhisperModel:
         rows that survive encode()'s truncation, 3x fewer connector FLOPs at L=512)."""
         if audio is None:
             raise ValueError("Audio input cannot be None")
-        if audio.dim() != 2 and (audio.dim() != 3 or audio.shape[1] != 80):
-            raise ValueError(f"Audio input should have shape [batch_size, sequence_length] or [batch_size, 80, time_steps], but got {audio.shape}")
+        nm = self.cfg.whisper.n_mels                               # the reference hard-codes 80 (:1074); lifted for whisper-large-v3 (128)
+        if audio.dim() != 2 and (audio.dim() != 3 or audio.shape[1] != nm):
+            raise ValueError(f"Audio input should have shape [batch_size, sequence_length] or [batch_size, {nm}, time_steps], but got {audio.shape}")
         if audio.dim() == 2:
-            raise ValueError("raw-waveform audio is not supported: pass WhisperFeatureExtractor mel features [B,80,3000]")
+            raise ValueError(f"raw-waveform audio is not supported: pass WhisperFeatureExtractor mel features [B,{nm},3000]")
         if self.whisper_engine is None:
             raise ValueError("audio encoder not loaded (modality=video)")
         h = self.whisper_engine.forward(audio)                       # [B,1500,d]

@@ -185,19 +185,26 @@ __global__ void im2col2_kernel(const T* __restrict__ h, T* __restrict__ cols, in
 }
 
 // ---------------------------------------------------------------- CLIP patchify: coalesced along frame rows
-template <typename T>
+template <typename T, int V>                      // V pixels per thread: 4 when the patch width allows it, 2 for patch 14 (ViT-L/14), else 1
 __global__ void patchify_kernel(const float* __restrict__ fr, T* __restrict__ cols, int N, int S, int p, int Kpad) {
-    const int g = S / p, pp = p * p;
-    const long total = (long)N * 3 * S * (S >> 2);
+    const int g = S / p, pp = p * p, SV = S / V;
+    const long total = (long)N * 3 * S * SV;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % (S >> 2)) * 4;
-        const int y = (int)((idx / (S >> 2)) % S);
-        const int c = (int)((idx / ((long)(S >> 2) * S)) % 3);
-        const long n = idx / ((long)(S >> 2) * S * 3);
-        const f32x4 v = *(const f32x4*)(fr + ((n * 3 + c) * S + y) * S + x);
+        const int x = (int)(idx % SV) * V;
+        const int y = (int)((idx / SV) % S);
+        const int c = (int)((idx / ((long)SV * S)) % 3);
+        const long n = idx / ((long)SV * S * 3);
+        const float* src = fr + ((n * 3 + c) * S + y) * S + x;
         const int py = y / p, ky = y % p, px = x / p, kx = x % p;
-        float o[4] = {v[0], v[1], v[2], v[3]};
-        store_f<4>(cols + (n * g * g + (long)py * g + px) * Kpad + c * pp + ky * p + kx, o);
+        T* dst = cols + (n * g * g + (long)py * g + px) * Kpad + c * pp + ky * p + kx;
+        if constexpr (V == 4) {
+            const f32x4 v = *(const f32x4*)src;
+            float o[4] = {v[0], v[1], v[2], v[3]};
+            store_f<4>(dst, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) dst[i] = from_f<T>(src[i]);
+        }
     }
 }
 template <typename T>
@@ -438,18 +445,21 @@ int av_whisper_im2col2(const void* h, void* cols, int B, int T, int d, int dtype
 
 int av_clip_patchify(const float* frames, void* cols, int N, int S, int p, int Kpad, int dtype, hipStream_t st) {
     AV_CHECK_ARG(frames && cols && N > 0, "patchify: bad args");
-    AV_CHECK_ARG(S % p == 0 && p % 4 == 0 && S % 4 == 0, "patchify: image %d / patch %d unsupported (patch must be a multiple of 4)", S, p);
+    AV_CHECK_ARG(p > 0 && S % p == 0, "patchify: image %d is not a whole number of %d-pixel patches", S, p);
     const int K = 3 * p * p;
     AV_CHECK_ARG(Kpad >= K && Kpad % 4 == 0, "patchify: Kpad=%d < %d", Kpad, K);
-    const long total = (long)N * 3 * S * (S / 4);
+    const int V = p % 4 == 0 ? 4 : p % 2 == 0 ? 2 : 1;
+    const long total = (long)N * 3 * S * (S / V);
     const long rows = (long)N * (S / p) * (S / p);
+#define AV_PATCHIFY(T, VV) hipLaunchKernelGGL((patchify_kernel<T, VV>), dim3(grid_for(total)), dim3(256), 0, st, frames, (T*)cols, N, S, p, Kpad)
     if (dtype == AV_F32) {
-        hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, frames, (float*)cols, N, S, p, Kpad);
+        if (V == 4) AV_PATCHIFY(float, 4); else if (V == 2) AV_PATCHIFY(float, 2); else AV_PATCHIFY(float, 1);
         if (Kpad > K) hipLaunchKernelGGL((patchify_pad_kernel<float>), dim3(grid_for(rows * (Kpad - K))), dim3(256), 0, st, (float*)cols, rows, K, Kpad);
     } else {
-        hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, frames, (bf16*)cols, N, S, p, Kpad);
+        if (V == 4) AV_PATCHIFY(bf16, 4); else if (V == 2) AV_PATCHIFY(bf16, 2); else AV_PATCHIFY(bf16, 1);
         if (Kpad > K) hipLaunchKernelGGL((patchify_pad_kernel<bf16>), dim3(grid_for(rows * (Kpad - K))), dim3(256), 0, st, (bf16*)cols, rows, K, Kpad);
     }
+#undef AV_PATCHIFY
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

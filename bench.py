@@ -34,7 +34,7 @@ FLOP_PER_CLIP = 11.64e12      # Whisper 0.344 + CLIP 4.391 + c
 
 def synthetic_batch(cfg, B, frames, seed, device):
     g = torch.Generator(device=device).manual_seed(seed)
-    audio = torch.randn(B, 80, 2 * cfg.whisper.n_ctx, generator=g, device=device)
+    audio = torch.randn(B, cfg.whisper.n_mels, 2 * cfg.whisper.n_ctx, generator=g, device=device)
     u8 = torch.randint(0, 256, (B, frames, 3, cfg.clip.image, cfg.clip.image), generator=g, device=device, dtype=torch.uint8)
     mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=device).view(1, 1, 3, 1, 1)
     std = torch.tensor([0.26862954, 0.26130258, 0.27577711], device=device).view(1, 1, 3, 1, 1)
@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
+    ap.add_argument("--whisper", default="openai/whisper-small", help="audio encoder by name (BASELINE config = whisper-small; config 5: openai/whisper-large-v3)")
+    ap.add_argument("--clip", default="openai/clip-vit-base-patch16", help="visual encoder by name (config 5: openai/clip-vit-large-patch14)")
     ap.add_argument("--llm", default="meta-llama/Llama-2-7b-hf", help="LLM architecture by name (BASELINE config = Llama-2-7B); e.g. "
                     "meta-llama/Meta-Llama-3-8B or TinyLlama/TinyLlama-1.1B for the grouped-query family")
     args = ap.parse_args()
@@ -108,10 +110,12 @@ def main():
         model = ClipWhisperModel(device=dev, max_seq_len=args.max_seq_len, config=cfg, precision=args.precision, seed=0)
         name = "tiny"
     else:
-        model = ClipWhisperModel(args.llm, "openai/whisper-small", "openai/clip-vit-base-patch16", device=dev,
+        model = ClipWhisperModel(args.llm, args.whisper, args.clip, device=dev,
                                  max_seq_len=args.max_seq_len, precision=args.precision, seed=0)
-        name = "whisper-small+clip-vit-b16->" + ("llama-2-7b" if "llama-2-7b" in args.llm.lower() else args.llm) + " lora r16"
-    default_llm = "llama-2-7b" in args.llm.lower()
+        base_enc = args.whisper == "openai/whisper-small" and args.clip == "openai/clip-vit-base-patch16"
+        name = ("whisper-small+clip-vit-b16" if base_enc else args.whisper.split("/")[-1] + "+" + args.clip.split("/")[-1]) + "->" + \
+               ("llama-2-7b" if "llama-2-7b" in args.llm.lower() else args.llm) + " lora r16"
+    default_llm = "llama-2-7b" in args.llm.lower() and (args.tiny or base_enc)
     cfg = model.cfg
     model.train()
     trainer = ClipWhisperTrainer(model, learning_rate=5e-5, weight_decay=0.01, grad_clip=0.5, total_steps=max(1000, args.steps + args.warmup))
@@ -152,7 +156,7 @@ def main():
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: " if default_llm and not args.tiny else "variant (not the BASELINE config): ") + f"{name}, synthetic LRS3-shaped 5 s clips ({args.frames} frames), "
+            "config": {"workload": ("BASELINE configs[1]: " if default_llm and not args.tiny else "variant (not the BASELINE config): ") + f"{name}, synthetic LRS3-shaped {args.frames / 25:g} s clips ({args.frames} frames), "
                                    f"max_seq_len {args.max_seq_len}, train seq 256", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "samples_per_s_per_gpu": round(value / world, 4),
                        "final_loss": round(final_loss, 5)},
@@ -166,7 +170,7 @@ def main():
                                "launches_per_step": int(prof[2] / args.steps),
                                "avg_launch_us": round(1000 * prof[0] / prof[2], 2), "gemm_ms_per_step": round(prof[0] / args.steps, 3),
                                "gemm_tflop_per_step": round(prof[1] / args.steps / 1e12, 3),
-                               "end_to_end_frac": round(frac_e2e, 4)}
+                               "end_to_end_frac": round(frac_e2e, 4) if default_llm and not args.tiny else None}     # FLOP_PER_CLIP is the BASELINE config's
         else:
             out["roofline"] = {"bound": "mfma", "achieved": round(value / world * FLOP_PER_CLIP / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": round(frac_e2e, 4), "traffic": None}

@@ -162,8 +162,9 @@ def encode(W, cfg, audio=None, video=None, prompt=None):
     encode_video :1108-1146, _embed_prompt :464-487."""
     a = v = None
     if audio is not None:
-        if audio.dim() != 3 or audio.shape[1] != 80:
-            raise ValueError(f"Audio input should have shape [batch_size, 80, time_steps], but got {tuple(audio.shape)}")
+        nm = cfg.whisper.n_mels              # the reference hard-codes 80 (:1074); 128 only for the whisper-large-v3 family (SURVEY.md §8f N3)
+        if audio.dim() != 3 or audio.shape[1] != nm:
+            raise ValueError(f"Audio input should have shape [batch_size, {nm}, time_steps], but got {tuple(audio.shape)}")
         a = connector(W["audio_connector"], whisper_encoder(W["whisper"], cfg.whisper, audio.float()))
     if video is not None:
         if video.dim() != 5 or video.shape[2] != 3:

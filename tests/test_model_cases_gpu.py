@@ -150,3 +150,28 @@ def test_grouped_query_llm_golden_and_oracle(dev, golden_dir):
         r_ = torch.from_numpy(g["grad." + k])
         num += float(((gr.cpu() - r_) ** 2).sum()); den += float((r_ ** 2).sum())
     assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+
+
+def test_config5_family_geometry_vs_oracle(dev):
+    """BASELINE config 5's encoder family at test size: a 128-mel Whisper (large-v3; the reference's 80-bin guard :1074 is lifted), a
+    patch-14 CLIP whose 224-pixel frames give 257 tokens per frame (the ViT-L/14 sequence length: general attention path, not the
+    197-token one-shot kernel), and a grouped-query LLM (Mistral layout).  Whole train step against the oracle, fp32 bars."""
+    oc = Wt.tiny()
+    oc.whisper = Wt.WhisperCfg(d_model=128, heads=2, layers=2, ffn=256, n_mels=128)
+    oc.clip = Wt.ClipCfg(hidden=128, heads=2, layers=2, mlp=256, image=224, patch=14)
+    oc.llama = Wt.LlamaCfg(hidden=256, heads=4, layers=2, ffn=512, vocab=256, kv_heads=2)
+    assert oc.clip.tokens == 257
+    W = Wt.all_weights(oc, 21, lora_b_std=0.05)
+    audio, video, labels, prompt = batch(oc, 2, 3, seed=9)
+    assert audio.shape[1] == 128
+    m = make_model(oc, W, "fp32")
+    check_train(dev, oc, W, m, audio, video, prompt, labels, 512)
+    with pytest.raises(ValueError, match="128"):
+        m.encode_audio(audio[:, :80].to(dev))                    # an 80-bin tensor is now the wrong shape for this encoder
+    m16 = make_model(oc, W, "bf16").train()
+    to = lambda t: t.to(dev)
+    o16 = m16(audio=to(audio), video=to(video), prompt=to(prompt), labels=to(labels))
+    cfg = copy.copy(oc); cfg.max_seq_len = 512
+    ref_loss, ref_logits, _ = O.train_step_grads(W, cfg, audio, video, prompt, labels)
+    err = (o16["logits"].float().cpu() - ref_logits).abs()
+    assert err.max() < 6e-2 and err.mean() < 1e-2 and abs(float(o16["loss"].detach()) - float(ref_loss)) < 2e-2
