@@ -100,6 +100,7 @@ _SIGS = {
     "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp], i32),
     "avllm_lora_pack": ([vp, vp, i32, i32, i32, vp, vp, i64, vp, vp, i32, vp], i32),
     "avllm_profile_begin": ([i32], i32),
+    "avllm_profile_enable": ([i32], i32),
     "avllm_profile_end": ([C.POINTER(C.c_double)], i32),
     "avllm_whisper_workspace_bytes": ([C.POINTER(Whisper), i32], sz),
     "avllm_whisper_encoder_fwd": ([C.POINTER(Whisper), vp, i32, vp, vp, sz, vp], i32),

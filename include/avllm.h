@@ -181,6 +181,7 @@ int avllm_clip_preproc(const void* plan, const uint8_t* frames, int32_t N, int32
  * calls) is bracketed by two HIP events on its stream.  out[0]=sum of GEMM ms, out[1]=sum of algorithmic FLOPs
  * (2*M*N*(K+K2)), out[2]=launches timed. */
 int avllm_profile_begin(int32_t max_launches);
+int avllm_profile_enable(int32_t on);      /* pause (0) / resume (1) bracketing between begin and end; recorded launches are kept */
 int avllm_profile_end(double* out);
 
 /* ---------------------------------------------------------------- model level ------------------ */
