@@ -108,6 +108,27 @@ def test_gemm_full_size_llama_shapes(dev):
         close(out, ref, 3e-2, 2e-2, f"gemm {M}x{N}x{K}")
 
 
+def test_gemm_full_size_clip_shapes(dev):
+    """CLIP ViT-B/16 projections at the bench size (16 clips x 125 frames x 197 tokens = 394000 rows, a ragged last row tile, 13860 tiles on
+    256 CUs through the persistent kernel): qkv with bias, fc1 with bias + quick-GELU, fc2 with bias + in-place residual, checked on a
+    sample of rows (first / last tile rows included) against fp32 torch."""
+    from avllm import lib as L
+    M = 394000
+    rows = torch.cat([torch.randperm(M, device=dev)[:1500], torch.tensor([0, 255, 256, M - 257, M - 1], device=dev)])
+    for N, K, act, res in ((2304, 768, L.ACT_NONE, False), (3072, 768, L.ACT_QUICK_GELU, False), (768, 3072, L.ACT_NONE, True)):
+        A, B = rnd(M, K, dtype=torch.bfloat16, seed=8), rnd(N, K, dtype=torch.bfloat16, seed=9, scale=K ** -0.5)
+        bias = rnd(N, dtype=torch.bfloat16, seed=10)
+        x = rnd(M, N, dtype=torch.bfloat16, seed=11) if res else None
+        xr = x[rows].float() if res else 0.0
+        out = ops.gemm(A, B, out=x, bias=bias, R=x, act=act) if res else ops.gemm(A, B, bias=bias, act=act)
+        ref = A[rows].float() @ B.float().t() + bias.float()
+        if act == L.ACT_QUICK_GELU:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        close(out[rows], ref + xr, 4e-2, 2e-2, f"clip gemm {M}x{N}x{K}")
+        del A, B, out, x
+        torch.cuda.empty_cache()
+
+
 def test_attention_full_size(dev):
     """Bench-size attention: Llama (B8,H32,T256,hd128 causal) fwd+bwd, Whisper (T1500) and CLIP (197) fwd vs torch SDPA."""
     import torch.nn.functional as F
