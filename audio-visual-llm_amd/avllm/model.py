@@ -72,6 +72,7 @@ class ClipWhisperModel:
         self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
         self.training = True
         self._drop_step = 0
+        self._seed = int(seed or 0)
 
         cfg, W = resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lora_r, lora_alpha, use_lora,
                               _provided_llm, _provided_whisper, _provided_clip, device, self.dtype)
@@ -167,8 +168,12 @@ class ClipWhisperModel:
 
     def _setup_projections(self, W=None):
         """clip_whisper_model.py:1159-1190: both connectors always exist."""
-        self.audio_connector = create_modality_connector(self.connector_type, self.audio_dim, self.llm_dim, self.device, self.dtype)
-        self.video_connector = create_modality_connector(self.connector_type, self.video_dim, self.llm_dim, self.device, self.dtype)
+        # xavier init as in the reference, but drawn from a private generator state derived from `seed` (the global RNG is left alone):
+        # two builds with the same seed are the same model, which the reference's unseeded nn.Linear init does not give
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(0x5EED + int(self._seed))
+            self.audio_connector = create_modality_connector(self.connector_type, self.audio_dim, self.llm_dim, self.device, self.dtype)
+            self.video_connector = create_modality_connector(self.connector_type, self.video_dim, self.llm_dim, self.device, self.dtype)
         if W is not None:
             if "audio_connector" in W:
                 self.audio_connector.load_state_dict(W["audio_connector"])

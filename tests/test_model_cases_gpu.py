@@ -175,3 +175,21 @@ def test_config5_family_geometry_vs_oracle(dev):
     ref_loss, ref_logits, _ = O.train_step_grads(W, cfg, audio, video, prompt, labels)
     err = (o16["logits"].float().cpu() - ref_logits).abs()
     assert err.max() < 6e-2 and err.mean() < 1e-2 and abs(float(o16["loss"].detach()) - float(ref_loss)) < 2e-2
+
+
+def test_same_seed_same_model(dev):
+    """Offline (synthetic) construction is a pure function of `seed`, connectors included (the reference draws its connector init from the
+    global RNG): two builds agree bit for bit whatever the global RNG state, a different seed gives a different model."""
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    cfg = lambda: ModelCfg(WhisperCfg(128, 2, 2, 256), ClipCfg(128, 2, 2, 256, 48, 16), LlamaCfg(256, 2, 2, 512, 256), LoraCfg(16, 32.0))
+    oc = Wt.tiny()
+    audio, video, labels, prompt = batch(oc, 2, 3, seed=4)
+    outs = []
+    for seed, gseed in ((3, 10), (3, 11), (4, 10)):
+        torch.manual_seed(gseed)
+        m = ClipWhisperModel(device=dev, max_seq_len=512, config=cfg(), precision="fp32", seed=seed).eval()
+        with torch.no_grad():
+            outs.append(m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))["logits"].clone())
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2])
