@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import glob
 import json
+import logging
 import math
 import os
 from dataclasses import dataclass, field
@@ -218,7 +219,11 @@ def _cfg_from_hf_dir(path, kind):
 
 
 def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lora_r, lora_alpha, use_lora, p_llm, p_whisper,
-                 p_clip, device, dtype):
+                 p_clip, device, dtype, synthetic_weights=False):
+    """-> (ModelCfg, weights).  A component's tensors come from `weights[kind]`, a `_provided_*` module, or a local HF directory with
+    safetensors.  Seeded random tensors of the named architecture are an explicit opt-in (`synthetic_weights=True`: bench, tests, the
+    scripts' --synthetic-weights); without it a path that is not a local checkpoint raises FileNotFoundError instead of silently
+    training / decoding a random model."""
     W = dict(weights or {})
     cfg = config
     if cfg is None:
@@ -255,8 +260,13 @@ def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lor
             sd = {k: v.detach() for k, v in prov.state_dict().items()}
         elif isinstance(path, str) and os.path.isdir(path) and glob.glob(os.path.join(path, "*.safetensors")):
             sd = _load_dir(path)
-        else:
+        elif synthetic_weights:
+            logging.warning("%s: no local checkpoint at %r -- using SEEDED RANDOM weights of that architecture (synthetic_weights=True)", kind, path)
             sd = synth(c, device, dtype, seed)
+        else:
+            raise FileNotFoundError(f"{kind}: {path!r} is not a local directory with *.safetensors (there is no network access to fetch it by "
+                                    "name); pass a checkpoint directory, `_provided_*` modules or `weights=`, or opt in to seeded random "
+                                    "weights with synthetic_weights=True / --synthetic-weights")
         if kind == "whisper":
             sd = _strip(sd, "model.")
         if kind == "clip":

@@ -240,7 +240,9 @@ class LlamaEngine:
                     lm.gB = self.lora_g[b[0]:b[1]].data_ptr()
         m.layer = C.cast(self.layers, C.POINTER(L.LlamaLayer))
         self.desc = m
-        self.ws = Workspace(device)
+        self.ws = Workspace(device)            # training: holds the saved activations between fwd_loss() and bwd()
+        self.ws_infer = Workspace(device)      # prefill / decode_step scratch: an eval forward or generate() between a training
+        self._last = None                      #   forward and its backward must not touch the saved activations
         self.acc = torch.zeros(2, dtype=torch.float32, device=device)     # [loss_sum, count]
         if self.use_lora:
             self.pack_lora()
@@ -299,15 +301,20 @@ class LlamaEngine:
         self.acc.zero_()
         L.check(lib.avllm_llama_lora_fwd_loss(C.byref(self.desc), L.ptr(x), L.ptr(labels), B, S, L.ptr(logits), L.ptr(self.acc),
                                               L.ptr(self.acc) + 4, L.ptr(ws), ws.numel(), L.stream_ptr()))
-        self._last = (B, S, labels)
+        self._last = (B, S, labels, ws.data_ptr(), ws.numel())
+        self.gen = getattr(self, "gen", 0) + 1          # identifies whose activations the workspace holds (checked by _LoraLoss.backward)
         return logits
 
     def bwd(self, grad_scale=1.0, count=None, after_layer=None):
         """Accumulates LoRA grads into self.lora_g (zero it first).  `count` = device float tensor holding the
         (possibly all-reduced) number of scored tokens; defaults to this rank's."""
         lib = L.load()
-        B, S, labels = self._last
-        ws = self.ws.get(lib.avllm_llama_train_workspace_bytes(C.byref(self.desc), B, S))
+        if self._last is None:
+            raise RuntimeError("LlamaEngine.bwd() without a preceding fwd_loss()")
+        B, S, labels, ws_ptr, ws_len = self._last
+        ws = self.ws.buf
+        if ws is None or ws.data_ptr() != ws_ptr or ws.numel() != ws_len:
+            raise RuntimeError("LlamaEngine.bwd(): the training workspace changed since fwd_loss() (the saved activations are gone)")
         cnt = self.acc[1:2] if count is None else count
         cb = L.LAYER_CB(lambda l, u: after_layer(l)) if after_layer is not None else L.LAYER_CB(0)
         L.check(lib.avllm_llama_lora_bwd(C.byref(self.desc), L.ptr(labels), B, S, L.ptr(cnt), grad_scale, L.ptr(ws), ws.numel(),
@@ -323,7 +330,7 @@ class LlamaEngine:
         B, S, _ = x.shape
         x = x.contiguous()
         Tmax = kc.shape[2]
-        ws = self.ws.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, S))
+        ws = self.ws_infer.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, S))
         last = torch.empty(B, self.cfg.vocab, device=self.device, dtype=torch.float32)
         full = torch.empty(B, S, self.cfg.vocab, device=self.device, dtype=self.dtype) if all_logits else None
         L.check(lib.avllm_llama_prefill(C.byref(self.desc), L.ptr(x), B, S, L.ptr(kc), L.ptr(vc), Tmax, L.ptr(last), L.ptr(full),
@@ -333,7 +340,7 @@ class LlamaEngine:
     def decode_step(self, ids, pos, kc, vc):
         lib = L.load()
         B = ids.shape[0]
-        ws = self.ws.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, 1))
+        ws = self.ws_infer.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, 1))
         logits = torch.empty(B, self.cfg.vocab, device=self.device, dtype=torch.float32)
         L.check(lib.avllm_llama_decode_step(C.byref(self.desc), L.ptr(ids.contiguous()), B, pos, L.ptr(kc), L.ptr(vc), kc.shape[2],
                                             L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))

@@ -97,7 +97,7 @@ _SIGS = {
     "avllm_clip_cls_rows": ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "avllm_fuse_pool": ([vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     "avllm_grad_sumsq": ([vp, i64, vp, vp], i32),
-    "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp], i32),
+    "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp], i32),
     "avllm_lora_pack": ([vp, vp, i32, i32, i32, vp, vp, i64, vp, vp, i32, vp], i32),
     "avllm_profile_begin": ([i32], i32),
     "avllm_profile_enable": ([i32], i32),

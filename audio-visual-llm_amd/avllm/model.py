@@ -6,7 +6,8 @@ Differences that are deliberate and documented:
   * precision: `use_fp16=True` selects the MI355X reduced-precision mode (bf16 storage / fp32 accumulate);
     `use_fp16=False` is strict fp32 (fp32 MFMA).  `precision="bf16"|"fp32"` overrides.
   * weights come from local HF checkpoints (safetensors) when the given paths exist, from `_provided_*`
-    modules' state_dict()s, or -- offline -- from a seeded synthetic initialisation of the named architecture.
+    modules' state_dict()s, from `weights=`, or -- only with `synthetic_weights=True` -- from a seeded synthetic
+    initialisation of the named architecture (a path that is none of these raises FileNotFoundError).
   * freeze_encoders=False / use_4bit=True are refused (out of scope).
 """
 from __future__ import annotations
@@ -31,12 +32,15 @@ class _LoraLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lora_param, model, loss_value):
         ctx.model = model
+        ctx.gen = model.llm_engine.gen
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         m = ctx.model
         eng = m.llm_engine
+        if eng.gen != ctx.gen:
+            raise RuntimeError("loss.backward(): another training forward ran since this loss was computed; its activations were overwritten")
         eng.lora_g.zero_()
         eng.bwd(grad_scale=float(grad_out))
         return eng.lora_g.clone(), None, None
@@ -48,7 +52,7 @@ class ClipWhisperModel:
                  lora_r=16, lora_alpha=32, lora_dropout=0.05, freeze_encoders=True, freeze_llm=False, modality="both",
                  max_seq_len=256, fusion_scale=0.5, connector_type="simple", _provided_tokenizer=None, _provided_llm=None,
                  _provided_whisper=None, _provided_clip=None, *, precision=None, config: ModelCfg | None = None,
-                 weights: dict | None = None, seed: int = 0):
+                 weights: dict | None = None, seed: int = 0, synthetic_weights: bool = False):
         if use_4bit:
             raise NotImplementedError("use_4bit (bitsandbytes nf4) is out of scope of the MI355X hot path (SURVEY.md §8)")
         if not freeze_encoders:
@@ -75,10 +79,11 @@ class ClipWhisperModel:
         self._seed = int(seed or 0)
 
         cfg, W = resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lora_r, lora_alpha, use_lora,
-                              _provided_llm, _provided_whisper, _provided_clip, device, self.dtype)
+                              _provided_llm, _provided_whisper, _provided_clip, device, self.dtype, synthetic_weights)
         cfg.max_seq_len, cfg.fusion_scale = max_seq_len, fusion_scale
         self.cfg = cfg
-        self.tokenizer = _provided_tokenizer or load_tokenizer(llm_path, cfg.llama.vocab)
+        # explicit `weights=` / `config=` builds (tests, bench) are synthetic by construction: they carry no tokenizer either
+        self.tokenizer = _provided_tokenizer or load_tokenizer(llm_path, cfg.llama.vocab, synthetic=synthetic_weights or weights is not None)
         if getattr(self.tokenizer, "pad_token_id", None) is None:
             self.tokenizer.pad_token_id = getattr(self.tokenizer, "eos_token_id", 2)      # pad = eos (:955-959)
         cfg.pad_token_id = self.tokenizer.pad_token_id

@@ -15,9 +15,11 @@ def _ld(t):
 
 
 def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, alpha=1.0, out_f32=False,
-         r_mod=0, remap=None, M=None, a_drop=None, n_valid=0):
+         r_mod=0, remap=None, M=None, a_drop=None, n_valid=0, drop=None):
     """out[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias) + R.  A [M,K] (row stride free), B [N,K].
-    a_drop=(seed, p): A is replaced by dropout(A) on the fly (bf16, N == 64 only)."""
+    a_drop=(seed, p): A is replaced by dropout(A) on the fly (bf16, N == 64 only).
+    drop=(seed, p): the product (before +R) is multiplied by the dropout mask keep(seed, m*N+n, p)/(1-p) -- the adapter's
+    input-gradient GEMM of the training backward (csrc/engine.hip)."""
     lib = L.load()
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
@@ -39,6 +41,8 @@ def gemm(A, B, out=None, bias=None, R=None, A2=None, B2=None, act=L.ACT_NONE, al
         d.g_in, d.g_out, d.g_off = remap
     if a_drop is not None:
         d.a_drop_seed, d.a_drop_p = a_drop[0] & 0xFFFFFFFF, a_drop[1]
+    if drop is not None:
+        d.drop_seed, d.drop_p = drop[0] & 0xFFFFFFFF, drop[1]
     d.n_valid = n_valid
     L.check(lib.avllm_gemm(C.byref(d), L.stream_ptr()))
     return out
@@ -185,9 +189,11 @@ def grad_sumsq(g, out):
     L.check(L.load().avllm_grad_sumsq(L.ptr(g), g.numel(), L.ptr(out), L.stream_ptr()))
 
 
-def adamw_step(p, g, m, v, lr, step, sumsq=None, max_norm=0.0, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.01, prescale=1.0):
+def adamw_step(p, g, m, v, lr, step, sumsq=None, max_norm=0.0, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.01, prescale=1.0, guard=None,
+               skipped=None):
+    """guard: device float (e.g. the step's loss_sum); a non-finite guard or sumsq makes the launch a no-op and bumps `skipped`."""
     L.check(L.load().avllm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
-                                      L.ptr(sumsq), max_norm, prescale, L.stream_ptr()))
+                                      L.ptr(sumsq), max_norm, prescale, L.ptr(guard), L.ptr(skipped), L.stream_ptr()))
 
 
 def whisper_im2col1(mel, Kpad, dtype):

@@ -43,14 +43,20 @@ class ByteTokenizer:
         return [self.decode(row, skip_special_tokens) for row in batch]
 
 
-def load_tokenizer(llm_path, vocab_size):
-    if isinstance(llm_path, str) and os.path.isdir(llm_path):
-        try:
-            from transformers import AutoTokenizer
-            tok = AutoTokenizer.from_pretrained(llm_path, local_files_only=True)
-            if tok.pad_token is None:
-                tok.pad_token = tok.eos_token
-            return tok
-        except Exception:
-            pass
-    return ByteTokenizer(vocab_size)
+_TOKENIZER_FILES = ("tokenizer.json", "tokenizer.model", "tokenizer_config.json")
+
+
+def load_tokenizer(llm_path, vocab_size, synthetic=False):
+    """The LLM directory's own tokenizer (errors while loading it propagate: a broken tokenizer must not silently become a byte
+    tokenizer).  The byte-level stand-in is used only in synthetic mode (no checkpoints offline) -- otherwise a path without
+    tokenizer files raises, and the caller can hand one over as `_provided_tokenizer`."""
+    if isinstance(llm_path, str) and os.path.isdir(llm_path) and any(os.path.exists(os.path.join(llm_path, f)) for f in _TOKENIZER_FILES):
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(llm_path, local_files_only=True)
+        if tok.pad_token is None:
+            tok.pad_token = tok.eos_token
+        return tok
+    if synthetic:
+        return ByteTokenizer(vocab_size)
+    raise FileNotFoundError(f"no tokenizer files ({', '.join(_TOKENIZER_FILES)}) under {llm_path!r}: pass _provided_tokenizer, or "
+                            "synthetic_weights=True for the byte-level stand-in")

@@ -39,6 +39,7 @@ class ClipWhisperTrainer:
         self.m = torch.zeros_like(eng.lora_p)
         self.v = torch.zeros_like(eng.lora_p)
         self.sumsq = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)
+        self.skipped = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)      # optimizer steps skipped on a non-finite loss / gradient
         self.reducer = LoraGradReducer(eng.lora_g, eng.per_layer, eng.cfg.layers)
 
     # ---- _setup_optimizer :171-232: AdamW(beta 0.9/0.95, eps 1e-8); cosine (with optional linear warmup)
@@ -84,22 +85,57 @@ class ClipWhisperTrainer:
         self.sumsq.zero_()
         ops.grad_sumsq(eng.lora_g, self.sumsq)
         self.global_step += 1
+        # NaN/Inf guard of trainer :444-452 without a host sync: a non-finite (all-reduced) loss sum or gradient norm makes the update a
+        # no-op on every rank alike (the all-reduce spreads the NaN), leaving lora_p, m and v untouched; `skipped_steps` counts them.
+        # The LR schedule and Adam's bias-correction count still advance on a skipped step (the reference's do not).
         ops.adamw_step(eng.lora_p, eng.lora_g, self.m, self.v, self.lr_at(self.global_step - 1), self.global_step, sumsq=self.sumsq,
-                       max_norm=self.grad_clip or 0.0, wd=self.weight_decay)
+                       max_norm=self.grad_clip or 0.0, wd=self.weight_decay, guard=acc[0:1], skipped=self.skipped)
         eng.pack_lora()
         return acc[0] / acc[1]
+
+    @property
+    def skipped_steps(self):
+        return int(self.skipped.item())
+
+    def _all_ranks_ok(self, ok):
+        """Data-parallel runs: a batch is trained on only if EVERY rank could unpack its share -- a rank that skipped on its own would
+        leave the others waiting in the step's all-reduces.  One 1-element MIN all-reduce per batch, only when distributed."""
+        if not is_dist():
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.model.llm_engine.lora_p.device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
 
     def _train_epoch(self, epoch):
         self.model.train()
         total, n, t0 = 0.0, 0, time.time()
         pending = []
+        failures = 0
         for i, batch in enumerate(self.train_dataloader):
+            # the reference logs and skips a batch on ANY exception (:492-507).  Host-side preparation (everything before the first
+            # collective) is where data errors surface; under DDP the skip is agreed between ranks first.
+            unpacked, err = None, None
             try:
-                audio, video, labels, prompt = self._unpack(batch)
-                loss = self.train_step(audio, video, labels, prompt)
-            except (ValueError, AssertionError) as e:           # reference swallows per-batch errors (:492-507)
-                logging.error(f"Error in batch {i}: {e}")
+                unpacked = self._unpack(batch)
+            except Exception as e:
+                err = e
+            if not self._all_ranks_ok(err is None):
+                logging.error(f"Error in batch {i}: {err if err is not None else 'another rank failed to prepare its batch'}")
+                failures += 1
+                if failures > 5:
+                    raise RuntimeError("more than 5 consecutive batches failed") from err
                 continue
+            try:
+                loss = self.train_step(*unpacked)
+            except (ValueError, AssertionError) as e:
+                if is_dist():
+                    raise                                        # mid-step: the other ranks are already inside the collectives
+                logging.error(f"Error in batch {i}: {e}")
+                failures += 1
+                if failures > 5:
+                    raise RuntimeError("more than 5 consecutive batches failed") from e
+                continue
+            failures = 0
             pending.append(loss)
             if (i + 1) % self.log_interval == 0 or i + 1 == len(self.train_dataloader):
                 vals = torch.stack(pending).float().cpu()

@@ -37,7 +37,8 @@ int av_fuse_pool(const void* a, int Ta, const void* v, int Tv, const void* promp
                  int S_out, int D, float fs, int dtype, hipStream_t st);
 int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st);
 int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                  float wd, int step, const float* sumsq, float max_norm, float grad_prescale, hipStream_t st);
+                  float wd, int step, const float* sumsq, float max_norm, float grad_prescale, const float* guard, float* skipped,
+                  hipStream_t st);
 int av_lora_pack(const float* A, const float* Bm, int r, int din, int dout, void* A_pad, void* AT_pad, long ld_at,
                  void* B_pad, void* BT_pad, int dtype, hipStream_t st);
 int av_kv_append(const void* k, const void* v, long ld, void* kc, void* vc, int B, int T, int pos0, int Tmax, int d,

@@ -1180,6 +1180,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgsF g) {
 
 }  // namespace
 
+// Per-device launch state: the CU count and the "dynamic LDS limit raised" flags belong to the device the call runs on
+// (one process may drive several GPUs; hipFuncSetAttribute applies to the current device's copy of the code object).
+struct GemmDevState { int ncu = 0; bool attr_base = false, attr_wp = false, attr_w = false, attr_h = false; };
+static GemmDevState g_gemm_dev[64];
+static GemmDevState* gemm_dev_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    GemmDevState* s = &g_gemm_dev[dev & 63];
+    if (!s->ncu && hipDeviceGetAttribute(&s->ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) s->ncu = 256;
+    return s;
+}
 static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave, 8 256x256 4-wave persistent (lean epilogue only)
 extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
@@ -1205,7 +1216,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
                          (!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->R || ((uintptr_t)d->R % 16 == 0 && d->ldr % 8 == 0)) &&
                          !getenv("AVLLM_NARROW_EPILOGUE");
     if (d->dtype == AV_BF16 && d->M <= 16 && d->N % 16 == 0 && d->K % (32 * SK_WAVES) == 0 && d->K2 % 32 == 0 && d->g_in == 0 &&
-        d->drop_p <= 0.f && g_gemm_variant <= 0) {
+        d->drop_p <= 0.f && d->a_drop_p <= 0.f && g_gemm_variant <= 0) {      // a_drop: the rank-side kernel below owns the fused mask
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
@@ -1235,11 +1246,11 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
         g.wide_epi = wide_ok;
-        static bool attr_set = false;
-        if (!attr_set) {
+        GemmDevState* ds = gemm_dev_state();
+        if (!ds->attr_base) {
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LNSTAGE * LSTAGE));
-            attr_set = true;
+            ds->attr_base = true;
         }
         const int variant = g_gemm_variant >= 0 ? g_gemm_variant : (g_gemm_variant = getenv("AVLLM_GEMM_VARIANT") ? atoi(getenv("AVLLM_GEMM_VARIANT")) : 0);
         constexpr int XBM = 256, XBN = 256;
@@ -1254,30 +1265,25 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
         const bool lean_ok = wide_ok && d->alpha == 1.f && d->drop_p <= 0.f && d->g_in <= 0 && !e.out_f32 && d->r_mod <= 0;
         if (d->M > 128 && (variant == 8 || auto_h) && lean_ok && d->K + d->K2 >= 128) {
-            static bool attr8 = false;
-            if (!attr8) {
+            if (!ds->attr_wp) {
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_wp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS));
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_wp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS));
-                attr8 = true;
+                ds->attr_wp = true;
             }
-            static int ncu8 = 0;
-            if (!ncu8) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu8, hipDeviceAttributeMultiprocessorCount, dev)); }
+            const int ncu8 = ds->ncu;
             if (d->K2 > 0) hipLaunchKernelGGL(gemm_bf16_wp_kernel<true>, dim3(xtiles < ncu8 ? xtiles : ncu8), dim3(256), WP_LDS, st, g);
             else hipLaunchKernelGGL(gemm_bf16_wp_kernel<false>, dim3(xtiles < ncu8 ? xtiles : ncu8), dim3(256), WP_LDS, st, g);
         } else if (d->M > 128 && (variant == 7 || (auto_h && (d->K + d->K2 >= 4096 || (d->K + d->K2 >= 2048 && xtiles >= 1024)))) && d->K + d->K2 >= 128) {
-            static bool attr7 = false;
-            if (!attr7) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE)); attr7 = true; }
+            if (!ds->attr_w) { AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE)); ds->attr_w = true; }
             hipLaunchKernelGGL(gemm_bf16_w_kernel, dim3(xtiles), dim3(256), 2 * HSTAGE, st, g);
         } else if (d->M > 128 && (variant == 5 || variant == 6 || auto_h)) {
             AV_CHECK_ARG(fits32 || variant == 6, "gemm: operand too large for the 256x256 kernel's 32-bit row offsets");
-            static bool attr4 = false;
-            if (!attr4) {
+            if (!ds->attr_h) {
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE));
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_hp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HSTAGE));
-                attr4 = true;
+                ds->attr_h = true;
             }
-            static int ncu = 0;
-            if (!ncu) { int dev = 0; AV_HIP(hipGetDevice(&dev)); AV_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
+            const int ncu = ds->ncu;
             if (variant != 6) hipLaunchKernelGGL(gemm_bf16_h_kernel, dim3(xtiles), dim3(1024), 2 * HSTAGE, st, g);
             else hipLaunchKernelGGL(gemm_bf16_hp_kernel, dim3(xtiles < ncu ? xtiles : ncu), dim3(1024), 2 * HSTAGE, st, g);
         } else if (d->M > 128 && (variant == 2 || auto_l)) {

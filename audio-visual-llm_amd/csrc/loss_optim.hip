@@ -118,7 +118,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // torch.optim.AdamW single-tensor rule (decoupled decay first), preceded by clip_grad_norm_'s scaling
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                             const float* __restrict__ sumsq, float max_norm, float prescale) {
+                             const float* __restrict__ sumsq, float max_norm, float prescale, const float* __restrict__ guard,
+                             float* __restrict__ skipped) {
+    // Non-finite step guard (trainer/clip_whisper_trainer.py:444-452 skips backward and the optimizer on a NaN/Inf loss): decided on the
+    // device from values every thread reads alike, so the step costs no host sync and p, m, v stay untouched when it is skipped.
+    const bool bad = (sumsq && !isfinite(sumsq[0])) || (guard && !isfinite(guard[0]));
+    if (bad) {
+        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1.0f);
+        return;
+    }
     float coef = prescale;
     if (sumsq && max_norm > 0.f) {
         const float norm = sqrtf(sumsq[0]) * prescale;
@@ -214,13 +222,14 @@ int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st) {
 }
 
 int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                  float wd, int step, const float* sumsq, float max_norm, float grad_prescale, hipStream_t st) {
+                  float wd, int step, const float* sumsq, float max_norm, float grad_prescale, const float* guard, float* skipped,
+                  hipStream_t st) {
     AV_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
     const float bc1 = 1.0f - (float)pow((double)b1, step);
     const float bc2s = (float)sqrt(1.0 - pow((double)b2, step));
     long blocks = (n + 255) / 256;
     blocks = blocks > 4096 ? 4096 : blocks;
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, sumsq, max_norm, grad_prescale);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, sumsq, max_norm, grad_prescale, guard, skipped);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

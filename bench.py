@@ -108,11 +108,11 @@ def main():
 
     if args.tiny:
         cfg = ModelCfg(WhisperCfg(128, 2, 2, 256), ClipCfg(128, 2, 2, 256, 48, 16), LlamaCfg(256, 2, 2, 512, 256), LoraCfg(16, 32.0))
-        model = ClipWhisperModel(device=dev, max_seq_len=args.max_seq_len, config=cfg, precision=args.precision, seed=0)
+        model = ClipWhisperModel(device=dev, max_seq_len=args.max_seq_len, config=cfg, precision=args.precision, seed=0, synthetic_weights=True)
         name = "tiny"
     else:
         model = ClipWhisperModel(args.llm, args.whisper, args.clip, device=dev,
-                                 max_seq_len=args.max_seq_len, precision=args.precision, seed=0)
+                                 max_seq_len=args.max_seq_len, precision=args.precision, seed=0, synthetic_weights=True)
         base_enc = args.whisper == "openai/whisper-small" and args.clip == "openai/clip-vit-base-patch16"
         name = ("whisper-small+clip-vit-b16" if base_enc else args.whisper.split("/")[-1] + "+" + args.clip.split("/")[-1]) + "->" + \
                ("llama-2-7b" if "llama-2-7b" in args.llm.lower() else args.llm) + " lora r16"

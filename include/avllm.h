@@ -132,11 +132,13 @@ int avllm_fuse_pool(const void* a, int32_t Ta, const void* v, int32_t Tv, const 
                     void* out, int32_t B, int32_t L, int32_t S_out, int32_t D, float fusion_scale, int32_t dtype,
                     void* stream);
 /* clip_grad_norm_ + AdamW (trainer/clip_whisper_trainer.py:457-464,171-232) on a flat fp32 buffer, no host sync:
- * sumsq accumulates sum(g^2); the step reads it, clips with coef=min(1,max_norm/(sqrt(sumsq)+1e-6)). */
+ * sumsq accumulates sum(g^2); the step reads it, clips with coef=min(1,max_norm/(sqrt(sumsq)+1e-6)).
+ * Non-finite guard (trainer :444-452 skips backward + optimizer on a NaN/Inf loss): when *sumsq or *guard (e.g. the step's
+ * loss_sum; may be NULL) is not finite the launch leaves p, m, v untouched and adds 1 to *skipped (device float, may be NULL). */
 int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
 int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t step, const float* sumsq, float max_norm,
-                     float grad_prescale, void* stream);
+                     float grad_prescale, const float* guard, float* skipped, void* stream);
 /* build the four padded operand images of one LoRA pair from the fp32 masters A [r,din], B [dout,r]:
  * A_pad [64,din], AT_pad [din,64] (row stride ld_at), B_pad [dout,64], BT_pad [64,dout] in `dtype` */
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,

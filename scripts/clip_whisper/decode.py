@@ -22,6 +22,7 @@ def main():
     p.add_argument("--temperature", type=float, default=1.0); p.add_argument("--load_lora", action="store_true")
     p.add_argument("--data_path"); p.add_argument("--test_manifest"); p.add_argument("--test_labels")
     p.add_argument("--synthetic", type=int, default=0); p.add_argument("--tiny", action="store_true"); p.add_argument("--frames", type=int, default=125)
+    p.add_argument("--synthetic-weights", action="store_true", help="seeded random weights + byte tokenizer (implied by --tiny)")
     a = p.parse_args()
     from avllm.config import merged
     from avllm.model import ClipWhisperModel
@@ -34,7 +35,8 @@ def main():
         from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
         kw["config"] = ModelCfg(WhisperCfg(128, 2, 2, 256), ClipCfg(128, 2, 2, 256, 48, 16), LlamaCfg(256, 2, 2, 512, 512), LoraCfg(16, 32.0))
     model = ClipWhisperModel(llm_path=cfg["llm_path"], whisper_model=cfg["whisper_model"], clip_model=cfg["clip_model"], device="cuda:0",
-                             use_fp16=bool(cfg.get("use_fp16")), use_lora=a.load_lora, modality=a.modality, max_seq_len=256, **kw).eval()
+                             use_fp16=bool(cfg.get("use_fp16")), use_lora=a.load_lora, modality=a.modality, max_seq_len=256,
+                             synthetic_weights=a.synthetic_weights or a.tiny, **kw).eval()
     if a.model_path:
         ck = torch.load(a.model_path, map_location="cpu", weights_only=True)
         sd = ck.get("model_state_dict", ck)

@@ -27,6 +27,9 @@ def parse_args():
     p.add_argument("--log_interval", type=int); p.add_argument("--save_every", type=int); p.add_argument("--resume_from")
     p.add_argument("--seed", type=int); p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic clips")
     p.add_argument("--frames", type=int, default=125); p.add_argument("--tiny", action="store_true")
+    p.add_argument("--synthetic-weights", action="store_true",
+                   help="seeded random weights + byte tokenizer when the model paths are not local checkpoints (implied by --tiny); "
+                        "without it such a path is an error")
     return p.parse_args()
 
 
@@ -75,7 +78,7 @@ def main():
                              lora_r=cfg.get("lora_r", 16), lora_alpha=cfg.get("lora_alpha", 32), lora_dropout=cfg.get("lora_dropout", 0.05),
                              freeze_encoders=cfg.get("freeze_encoders", True), modality=cfg.get("modality", "both"),
                              max_seq_len=cfg.get("max_seq_len", 256), fusion_scale=cfg.get("fusion_scale", 0.5),
-                             connector_type=cfg.get("connector_type", "simple"), **kw)
+                             connector_type=cfg.get("connector_type", "simple"), synthetic_weights=a.synthetic_weights or a.tiny, **kw)
     if a.synthetic:
         frames = a.frames if not a.tiny else 5
         ds = SyntheticClips(a.synthetic, model.cfg, frames, model.tokenizer, cfg.get("seed", 42))

@@ -1,0 +1,42 @@
+"""Parity bars of the test-suite, stated ONCE (the tests import them; nothing restates a number).
+
+fp32 mode (`precision="fp32"`: fp32 storage, exact-fp32 MFMA `v_mfma_f32_16x16x4_f32`) carries the north-star bar of
+BASELINE.json: logits within 1e-3 of the reference, greedy tokens identical.  Observed differences are 1e-5 .. 5e-5 (summation
+order only), so the bars below are the north-star's, not the observed ones.
+
+bf16 mode (`precision="bf16"`: bf16 storage, fp32 accumulate / softmax / norm statistics / loss -- the arithmetic bench.py times)
+cannot hold 1e-3 absolute through a transformer stack (SURVEY.md §7 "Hard parts"), so its bar is derived instead of observed:
+
+  * bf16 keeps 8 significant bits: unit roundoff u = 2^-9 = 1.95e-3; a stored value carries a uniformly distributed relative
+    rounding error of RMS u/sqrt(3) = 1.13e-3.
+  * every tensor written to HBM is rounded once.  On the residual path of one decoder layer that is n ~ 8 roundings (normed input,
+    q|k|v, attention output, o-projection+residual, normed input, gate|up, SwiGLU product, down-projection+residual); independent
+    roundings add in quadrature, so after L layers the relative L2 error of the hidden state is about 1.13e-3 * sqrt(8 L):
+    0.3 % for one layer, 0.45 % for the 2-layer golden model, 1.8 % for 32 layers.  The bf16 weights add one more rounding per
+    product (same size, already in the sqrt).
+  * the backward pass runs the same chain again on dY (another sqrt(2)) and the LoRA gradients are reductions over tokens of
+    products of two rounded tensors: ~2x the forward figure.
+  * bars = 4x these estimates at the depth the tests run (<= 2 layers), rounded up: a systematic error (a wrong mask, a dropped
+    term, a mis-indexed tile) shows up as tens of percent and cannot hide under them.
+
+The looser absolute logit bars (max / mean) are the same statement for O(1) logits and are kept for the golden-vector tests.
+"""
+
+# ---- fp32 mode: BASELINE.json north-star
+F32_LOGITS_ABS = 1e-3            # max |logits - reference|
+F32_LOSS_ABS = 1e-4
+F32_GRAD_REL_MAX = 2e-4          # max |g - ref| <= this * max|ref| per LoRA tensor
+
+# ---- bf16 mode (derived above)
+BF16_LOGITS_REL_L2 = 2e-2        # ||logits - ref|| / ||ref|| over the whole tensor
+BF16_LOGIT_MAX_ABS = 6e-2        # x max(1, max|ref|): tail of the same distribution over ~1e5 logits
+BF16_LOGIT_MEAN_ABS = 1e-2
+BF16_LOSS_ABS = 2e-2
+BF16_GRAD_REL_L2 = 5e-2          # whole LoRA gradient, relative L2
+BF16_GRAD_TENSOR_REL_L2 = 1e-1   # any single LoRA tensor (small tensors are noisier)
+BF16_ENC_REL_L2 = 2e-2           # encoder outputs (Whisper hidden states, CLIP CLS), relative L2
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float(((a - b) ** 2).sum().sqrt() / (b ** 2).sum().sqrt().clamp_min(1e-30))

@@ -66,3 +66,60 @@ def test_two_ranks_equal_one_process(dev):
     init = _build("cuda:0")[0].llm_engine.lora_p.cpu()
     rel = ((params - ref).norm() / (ref - init).norm()).item()
     assert rel < 2e-2, rel                                   # relative to the size of the 2-step update
+
+
+def _rccl_worker(port, q):
+    """world_size 1 over the `nccl` backend (= RCCL): the code bench.py / train.py run on the 8-GPU node -- init with device_id,
+    the token-count all-reduce on the compute stream, 32-bucket-style async all-reduces on the side stream from the C callback,
+    work.wait() + stream join before the optimizer -- executes for real, on the one GPU this box has."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    m, tr, audio, video, labels, prompt = _build("cuda:0")
+    assert not tr.reducer.enabled                       # world_size 1 is not "distributed" ...
+    tr.reducer.enabled = True                           # ... so the reducer is forced on: every collective of the N > 1 path is issued
+    calls = []
+    orig = tr.reducer.layer_done
+    tr.reducer.layer_done = lambda layer: (calls.append(layer), orig(layer))[1]
+    losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(2)]
+    torch.cuda.synchronize()
+    q.put((losses, m.llm_engine.lora_p.cpu().numpy(), calls, dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_world_size_1_matches_non_distributed(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(31700 + os.getpid() % 2000, q))
+    p.start()
+    losses, params, calls, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and backend == "nccl"
+    assert calls == [1, 0, 1, 0]                        # one bucket per decoder layer, last layer first, both steps
+    m, tr, audio, video, labels, prompt = _build("cuda:0")
+    ref_losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(2)]
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-4, (losses, ref_losses)
+    ref = m.llm_engine.lora_p.cpu()
+    init = _build("cuda:0")[0].llm_engine.lora_p.cpu()
+    rel = ((torch.from_numpy(params) - ref).norm() / (ref - init).norm()).item()
+    assert rel < 2e-2, rel
+
+
+def test_bench_two_rank_launch_rehearsal(dev):
+    """bench.py under the driver's own launch line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), rehearsed on
+    one card (AVLLM_BENCH_SHARED_GPU=1: both ranks on cuda:0, gloo): rank/world plumbing, barriers, MAX over ranks and the ONE JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, AVLLM_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 33700 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tiny", "--batch", "2", "--frames", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+    assert "cpu_baseline" not in out                     # rank 0 at N = 1 only

@@ -107,3 +107,22 @@ def test_ddp_two_ranks_equal_single_process_on_concatenated_batch():
         assert p.exitcode == 0
     assert err <= 1e-5 * max(1.0, scale) + 1e-7, (err, scale)
     assert abs(loss_ddp - loss_ref) < 1e-5
+
+
+def test_unresolvable_model_paths_raise_instead_of_random_weights(tmp_path):
+    """A model path that is not a local checkpoint (the default YAML's `meta-llama/Llama-2-7b-hf`, or a typo) must not silently become a
+    seeded-random model with a byte tokenizer: FileNotFoundError unless synthetic_weights=True was asked for."""
+    import pytest
+    from avllm.arch import resolve_arch
+    from avllm.tokenizer import ByteTokenizer, load_tokenizer
+    args = ("meta-llama/Llama-2-7b-hf", "openai/whisper-small", "openai/clip-vit-base-patch16", None, None, 0, 16, 32, True, None, None, None,
+            "cpu", torch.float32)
+    with pytest.raises(FileNotFoundError, match="synthetic_weights"):
+        resolve_arch(*args)
+    with pytest.raises(FileNotFoundError):
+        load_tokenizer(str(tmp_path), 32000)                      # a directory without tokenizer files
+    assert isinstance(load_tokenizer(str(tmp_path), 32000, synthetic=True), ByteTokenizer)
+    (tmp_path / "tokenizer.json").write_text("{ not json")
+    with pytest.raises(Exception) as ei:                            # a BROKEN tokenizer must surface, not turn into the byte stand-in
+        load_tokenizer(str(tmp_path), 32000, synthetic=True)
+    assert not isinstance(ei.value, FileNotFoundError) or "tokenizer files" not in str(ei.value)

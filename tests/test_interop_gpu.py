@@ -44,7 +44,9 @@ def test_hf_checkpoints_load_and_match_oracle(dev, tmp_path, how):
     from oracle.make_golden import gqa_cfg
     cfg = gqa_cfg()                                          # grouped-query LLM, so num_key_value_heads travels through config.json
     whisper, clip, llm = hf_models(cfg)
-    kw = dict(device=dev, lora_r=cfg.lora.r, lora_alpha=cfg.lora.alpha, lora_dropout=0.0, max_seq_len=512, precision="fp32")
+    from avllm.tokenizer import ByteTokenizer
+    kw = dict(device=dev, lora_r=cfg.lora.r, lora_alpha=cfg.lora.alpha, lora_dropout=0.0, max_seq_len=512, precision="fp32",
+              _provided_tokenizer=ByteTokenizer(cfg.llama.vocab))       # the written checkpoints carry no tokenizer files
     if how == "directories":
         dirs = {}
         for name, mod in (("whisper", whisper), ("clip", clip), ("llama", llm)):

@@ -99,13 +99,19 @@ def test_fused_dropout_equals_materialised(dev, M, K):
 
 
 def test_gemm_full_size_llama_shapes(dev):
-    """Llama-2-7B projection shapes at the bench batch (M = 8*256): against torch.matmul on the device."""
-    M = 2048
-    for N, K in ((4096, 4096), (22016, 4096), (4096, 11008), (32000, 4096)):
+    """Llama-2-7B projection shapes at the bench batch (M = 16*256 = 4096 rows: the persistent 4-wave kernel's grids), with and without the
+    LoRA second K segment, against an fp32 torch product on a sample of rows (first / last rows of tiles included)."""
+    M = 4096
+    rows = torch.cat([torch.randperm(M, device=dev)[:384], torch.tensor([0, 127, 128, 255, 256, M - 257, M - 1], device=dev)])
+    for N, K in ((4096, 4096), (12288, 4096), (22016, 4096), (4096, 11008), (32000, 4096)):
         A, B = rnd(M, K, dtype=torch.bfloat16, seed=6), rnd(N, K, dtype=torch.bfloat16, seed=7, scale=K ** -0.5)
         out = ops.gemm(A, B)
-        ref = (A @ B.t()).float()
-        close(out, ref, 3e-2, 2e-2, f"gemm {M}x{N}x{K}")
+        ref = A[rows].float() @ B.float().t()
+        close(out[rows], ref, 2e-2, 1e-2, f"gemm {M}x{N}x{K}")
+        if N <= 12288:
+            A2, B2 = rnd(M, 64, dtype=torch.bfloat16, seed=8), rnd(N, 64, dtype=torch.bfloat16, seed=9, scale=0.1)
+            out2 = ops.gemm(A, B, A2=A2, B2=B2)
+            close(out2[rows], ref + A2[rows].float() @ B2.float().t(), 2e-2, 1e-2, f"gemm+lora {M}x{N}x{K}+64")
 
 
 def test_gemm_full_size_clip_shapes(dev):

@@ -10,7 +10,7 @@ from avllm.model import ClipWhisperModel
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--new", type=int, default=64); ap.add_argument("--frames", type=int, default=125)
 a = ap.parse_args()
-m = ClipWhisperModel(device="cuda:0", max_seq_len=256, precision="bf16", use_lora=False).eval()
+m = ClipWhisperModel(device="cuda:0", max_seq_len=256, precision="bf16", use_lora=False, synthetic_weights=True).eval()
 m.eos_token_id = None                                    # random weights: never stop early
 g = torch.Generator(device="cuda").manual_seed(1)
 audio = torch.randn(a.batch, 80, 3000, device="cuda", generator=g)
