@@ -227,7 +227,8 @@ def test_g3_bench_shape_bf16_with_lora_dropout(dev, llama7b_layer):
     wrong = dict(masks)
     wrong["layers.0.o_proj"] = masks["layers.0.q_proj"]
     _, _, og2 = _oracle_llm_step(sd, lora, c, lc, x.float(), labels, masks=wrong)
-    assert rel_l2(grads["layers.0.o_proj.lora_A"], og2["layers.0.o_proj.lora_A"]) > 4 * Bar.BF16_GRAD_TENSOR_REL_L2
+    # (p = 0.05: the two masks differ on ~2p of the elements -> relative error ~ sqrt(2p/(1-p)) = 0.32, three times the bar)
+    assert rel_l2(grads["layers.0.o_proj.lora_A"], og2["layers.0.o_proj.lora_A"]) > 2.5 * Bar.BF16_GRAD_TENSOR_REL_L2
     # the same step through the 16-wave tiling (every projection) against the automatic choice (persistent 4-wave)
     lib = L.load()
     try:
