@@ -54,6 +54,21 @@ class LoraGradReducer:
         else:
             self.work.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def layers_done(self, lo: int, hi: int):
+        """Graph-replayed backward pieces: all-reduce the contiguous gradient slice of decoder layers lo..hi (inclusive) on the side stream,
+        ordered after everything enqueued on the compute stream so far (the piece that produced it)."""
+        if not self.enabled:
+            return
+        bucket = self.g[lo * self.per_layer:(hi + 1) * self.per_layer]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                self.work.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.work.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def finish(self):
         """Join the side stream before the optimizer reads the gradients."""
         for w in self.work:

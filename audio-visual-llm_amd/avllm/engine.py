@@ -287,12 +287,14 @@ class LlamaEngine:
                                           L.stream_ptr()))
 
     # ------------------------------------------------------------------ training
-    def fwd_loss(self, x, labels, want_logits=False, dropout=0.0, seed=0):
+    def fwd_loss(self, x, labels, want_logits=False, dropout=0.0, seed=0, seed_dev=None):
         """x [B,S,d] (engine dtype), labels int64 [B,S] (-100 applied).  Leaves loss_sum,count in self.acc.
-        `dropout`/`seed`: lora_dropout probability and the step's mask seed (kept in the descriptor for bwd())."""
+        `dropout`/`seed`: lora_dropout probability and the step's mask seed (kept in the descriptor for bwd()); `seed_dev`: device
+        pointer (int) of a uint32 added to `seed` at run time -- the step state of a graph-replayable step."""
         lib = L.load()
         self.desc.lora_dropout = float(dropout) if self.use_lora else 0.0
         self.desc.dropout_seed = int(seed) & 0xFFFFFFFF
+        self.desc.dropout_seed_dev = seed_dev
         B, S, _ = x.shape
         x = x.contiguous()
         labels = labels.contiguous()
@@ -305,9 +307,10 @@ class LlamaEngine:
         self.gen = getattr(self, "gen", 0) + 1          # identifies whose activations the workspace holds (checked by _LoraLoss.backward)
         return logits
 
-    def bwd(self, grad_scale=1.0, count=None, after_layer=None):
+    def bwd(self, grad_scale=1.0, count=None, after_layer=None, layer_hi=None, layer_lo=0):
         """Accumulates LoRA grads into self.lora_g (zero it first).  `count` = device float tensor holding the
-        (possibly all-reduced) number of scored tokens; defaults to this rank's."""
+        (possibly all-reduced) number of scored tokens; defaults to this rank's.  layer_hi/layer_lo: run only that piece of the
+        backward pass (decoder layers layer_hi .. layer_lo; pieces in descending order, avllm_llama_lora_bwd_layers)."""
         lib = L.load()
         if self._last is None:
             raise RuntimeError("LlamaEngine.bwd() without a preceding fwd_loss()")
@@ -317,8 +320,9 @@ class LlamaEngine:
             raise RuntimeError("LlamaEngine.bwd(): the training workspace changed since fwd_loss() (the saved activations are gone)")
         cnt = self.acc[1:2] if count is None else count
         cb = L.LAYER_CB(lambda l, u: after_layer(l)) if after_layer is not None else L.LAYER_CB(0)
-        L.check(lib.avllm_llama_lora_bwd(C.byref(self.desc), L.ptr(labels), B, S, L.ptr(cnt), grad_scale, L.ptr(ws), ws.numel(),
-                                         cb, None, L.stream_ptr()))
+        hi = self.cfg.layers - 1 if layer_hi is None else layer_hi
+        L.check(lib.avllm_llama_lora_bwd_layers(C.byref(self.desc), L.ptr(labels), B, S, L.ptr(cnt), grad_scale, L.ptr(ws), ws.numel(),
+                                                hi, layer_lo, cb, None, L.stream_ptr()))
 
     # ------------------------------------------------------------------ inference
     def alloc_cache(self, B, Tmax):

@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("A2", vp), ("B2", vp), ("C", vp), ("bias", vp), ("R", vp),
                 ("lda", i64), ("ldb", i64), ("lda2", i64), ("ldb2", i64), ("ldc", i64), ("ldr", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("K2", i32), ("dtype", i32), ("out_f32", i32), ("act", i32),
-                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32), ("a_drop_seed", C.c_uint32), ("a_drop_p", f32), ("n_valid", i32)]
+                ("alpha", f32), ("r_mod", i32), ("g_in", i32), ("g_out", i32), ("g_off", i32), ("drop_seed", C.c_uint32), ("drop_p", f32), ("a_drop_seed", C.c_uint32), ("a_drop_p", f32), ("n_valid", i32), ("seed_dev", vp)]
 
 
 class EncLayer(C.Structure):
@@ -57,7 +57,17 @@ class LlamaLayer(C.Structure):
 class Llama(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "vocab", "lora_r", "kv_heads")] + \
                [(n, f32) for n in ("eps", "theta", "lora_scale", "lora_dropout")] + [("dropout_seed", C.c_uint32)] + \
-               [(n, vp) for n in ("embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))]
+               [(n, vp) for n in ("dropout_seed_dev", "embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))]
+
+
+class StepState(C.Structure):
+    """avllm_step_state: per-step scalars in DEVICE memory (this mirror is only used for sizes / field offsets / host reads)."""
+    _fields_ = [("step", C.c_uint32), ("dropout_seed", C.c_uint32), ("lr", f32), ("bc1", f32), ("bc2_sqrt", f32), ("skipped", f32),
+                ("reserved", C.c_uint32 * 2)]
+
+
+class Schedule(C.Structure):
+    _fields_ = [("base_lr", f32), ("beta1", f32), ("beta2", f32), ("warmup_steps", i32), ("total_steps", i32), ("rank", C.c_uint32)]
 
 
 LAYER_CB = C.CFUNCTYPE(None, i32, vp)
@@ -97,7 +107,9 @@ _SIGS = {
     "avllm_clip_cls_rows": ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "avllm_fuse_pool": ([vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     "avllm_grad_sumsq": ([vp, i64, vp, vp], i32),
-    "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp], i32),
+    "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp, vp], i32),
+    "avllm_step_advance": ([vp, C.POINTER(Schedule), vp], i32),
+    "avllm_llama_lora_bwd_layers": ([C.POINTER(Llama), vp, i32, i32, vp, f32, vp, sz, i32, i32, LAYER_CB, vp, vp], i32),
     "avllm_lora_pack": ([vp, vp, i32, i32, i32, vp, vp, i64, vp, vp, i32, vp], i32),
     "avllm_profile_begin": ([i32], i32),
     "avllm_profile_enable": ([i32], i32),

@@ -271,9 +271,10 @@ class ClipWhisperModel:
                 labels = torch.stack(labels)
             else:
                 labels = torch.tensor(labels)
-        labels = labels.to(self.device).clone()
-        labels[labels == self.tokenizer.pad_token_id] = -100          # :569-570
-        return labels
+        labels = labels.to(self.device)
+        # :569-570 `labels[labels == pad] = -100` as one fresh tensor (no boolean-index assignment: that form syncs with the host and
+        # cannot be captured in a graph)
+        return torch.where(labels == self.tokenizer.pad_token_id, torch.full_like(labels, -100), labels)
 
     def forward(self, audio=None, video=None, prompt=None, labels=None, return_loss=True):
         """clip_whisper_model.py:489-619 -> {"loss","logits"} | {"logits"}."""

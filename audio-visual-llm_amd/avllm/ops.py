@@ -190,10 +190,17 @@ def grad_sumsq(g, out):
 
 
 def adamw_step(p, g, m, v, lr, step, sumsq=None, max_norm=0.0, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.01, prescale=1.0, guard=None,
-               skipped=None):
-    """guard: device float (e.g. the step's loss_sum); a non-finite guard or sumsq makes the launch a no-op and bumps `skipped`."""
+               skipped=None, state=None):
+    """guard: device float (e.g. the step's loss_sum); a non-finite guard or sumsq makes the launch a no-op and bumps `skipped`.
+    state: device avllm_step_state (uint8 tensor): lr and Adam's bias corrections are read from it instead of `lr` / `step`."""
     L.check(L.load().avllm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
-                                      L.ptr(sumsq), max_norm, prescale, L.ptr(guard), L.ptr(skipped), L.stream_ptr()))
+                                      L.ptr(sumsq), max_norm, prescale, L.ptr(guard), L.ptr(skipped), L.ptr(state), L.stream_ptr()))
+
+
+def step_advance(state, base_lr, total_steps, warmup_steps=0, beta1=0.9, beta2=0.95, rank=0):
+    """One-thread kernel: state.step += 1 and this step's lr / bias corrections / dropout seed (include/avllm.h avllm_step_state)."""
+    sc = L.Schedule(base_lr, beta1, beta2, int(warmup_steps), int(total_steps), int(rank))
+    L.check(L.load().avllm_step_advance(L.ptr(state), C.byref(sc), L.stream_ptr()))
 
 
 def whisper_im2col1(mel, Kpad, dtype):

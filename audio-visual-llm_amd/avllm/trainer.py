@@ -4,10 +4,18 @@ same constructor keywords, batch layouts, return dict and output files.  The ste
   encoders (HIP) -> fuse/pool (HIP) -> Llama+LoRA fwd+loss (HIP) -> bwd (HIP) [-> RCCL all-reduce, overlapped]
   -> clip_grad_norm_ + AdamW fused on the flat LoRA buffer (HIP) -> cosine LR.
 No `loss.item()` inside the step: the loss stays on the device and is read once per log interval.
+
+The step is graph-replayable: everything that changes from step to step (learning rate, Adam's bias corrections, the LoRA dropout
+seed) lives in a small device record advanced by a one-thread kernel at the top of the step (include/avllm.h avllm_step_state), so the
+~1,400 kernel launches of a step are the same sequence every time.  With `use_graph` (default on) the step is captured once per input
+signature into hipGraphs (torch.cuda.CUDAGraph owns capture + memory pool) and replayed: one graph when single-process; under data
+parallelism forward / backward pieces / optimizer are separate graphs with the RCCL collectives issued between them, each backward
+piece's gradient all-reduce running on the side stream under the next piece.
 """
 from __future__ import annotations
 
 import csv
+import ctypes
 import json
 import logging
 import math
@@ -16,6 +24,7 @@ import time
 
 import torch
 
+from . import lib as L
 from . import ops
 from .dist import LoraGradReducer, is_dist
 
@@ -23,7 +32,8 @@ from .dist import LoraGradReducer, is_dist
 class ClipWhisperTrainer:
     def __init__(self, model, train_dataloader=None, val_dataloader=None, learning_rate=5e-5, weight_decay=0.01, max_epochs=10,
                  output_dir="outputs/clip_whisper", device="cuda", fp16=False, grad_accum_steps=1, log_interval=10, save_every=1,
-                 save_steps=None, grad_clip=0.5, warmup_steps=0, log_param_updates=False, total_steps=None):
+                 save_steps=None, grad_clip=0.5, warmup_steps=0, log_param_updates=False, total_steps=None, use_graph=None,
+                 bwd_pieces=None):
         self.model, self.train_dataloader, self.val_dataloader = model, train_dataloader, val_dataloader
         self.learning_rate, self.weight_decay, self.max_epochs = learning_rate, weight_decay, max_epochs
         self.output_dir, self.device, self.fp16 = output_dir, device, fp16
@@ -41,6 +51,18 @@ class ClipWhisperTrainer:
         self.sumsq = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)
         self.skipped = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)      # optimizer steps skipped on a non-finite loss / gradient
         self.reducer = LoraGradReducer(eng.lora_g, eng.per_layer, eng.cfg.layers)
+        dev = eng.lora_p.device
+        # avllm_step_state on the device: step count, this step's lr / bias corrections / dropout seed
+        self.state = torch.zeros(ctypes.sizeof(L.StepState), dtype=torch.uint8, device=dev)
+        self._seed_ptr = self.state.data_ptr() + L.StepState.dropout_seed.offset
+        self._loss_buf = torch.zeros((), dtype=torch.float32, device=dev)
+        self._rank = torch.distributed.get_rank() if is_dist() else 0
+        if use_graph is None:
+            use_graph = os.environ.get("AVLLM_GRAPH", "1") != "0"
+        self.use_graph = bool(use_graph) and dev.type == "cuda"
+        # data parallel + graphs: the backward pass is replayed in pieces so that a piece's gradient all-reduce overlaps the next piece
+        self.bwd_pieces = max(1, min(eng.cfg.layers, bwd_pieces if bwd_pieces is not None else (4 if is_dist() else 1)))
+        self._graphs = {}
 
     # ---- _setup_optimizer :171-232: AdamW(beta 0.9/0.95, eps 1e-8); cosine (with optional linear warmup)
     def lr_at(self, step):
@@ -72,26 +94,138 @@ class ClipWhisperTrainer:
                 raise AssertionError(f"Batch size mismatch: {t.shape[0]} vs labels {bs}")
         return audio, video, labels, tok.input_ids
 
-    def train_step(self, audio, video, labels, prompt):
-        """One optimizer step on this rank's batch; returns the (global) mean loss as a device scalar."""
+    # ---- the step, in capture-safe parts (no host sync, no host-side per-step scalars)
+    def _part_fwd(self, audio, video, labels, prompt):
         model, eng = self.model, self.model.llm_engine
+        ops.step_advance(self.state, self.learning_rate, self.total_steps, self.warmup_steps, rank=self._rank)
         labels = model._prep_labels(labels)
         x = model._llm_inputs(audio, video, prompt, S_out=labels.shape[1])
-        eng.fwd_loss(x, labels, **model._dropout_args())
-        acc = self.reducer.reduce_counts(eng.acc)
-        eng.lora_g.zero_()
-        eng.bwd(grad_scale=1.0, count=acc[1:2], after_layer=self.reducer.layer_done if self.reducer.enabled else None)
-        self.reducer.finish()
+        p = float(model.lora_dropout) if (model.training and model.use_lora and model.lora_dropout) else 0.0
+        eng.fwd_loss(x, labels, dropout=p, seed=0, seed_dev=self._seed_ptr)
+
+    def _piece_range(self, i):
+        """Decoder layers (hi, lo) of backward piece i of self.bwd_pieces, last layer first."""
+        n, k = self.model.llm_engine.cfg.layers, self.bwd_pieces
+        hi = n - 1 - (i * n) // k
+        lo = n - ((i + 1) * n) // k
+        return hi, lo
+
+    def _part_bwd(self, i, per_layer_cb=None):
+        eng = self.model.llm_engine
+        if i == 0:
+            eng.lora_g.zero_()
+        hi, lo = self._piece_range(i)
+        eng.bwd(grad_scale=1.0, count=eng.acc[1:2], after_layer=per_layer_cb, layer_hi=hi, layer_lo=lo)
+
+    def _part_opt(self):
+        eng = self.model.llm_engine
         self.sumsq.zero_()
         ops.grad_sumsq(eng.lora_g, self.sumsq)
-        self.global_step += 1
         # NaN/Inf guard of trainer :444-452 without a host sync: a non-finite (all-reduced) loss sum or gradient norm makes the update a
         # no-op on every rank alike (the all-reduce spreads the NaN), leaving lora_p, m and v untouched; `skipped_steps` counts them.
         # The LR schedule and Adam's bias-correction count still advance on a skipped step (the reference's do not).
-        ops.adamw_step(eng.lora_p, eng.lora_g, self.m, self.v, self.lr_at(self.global_step - 1), self.global_step, sumsq=self.sumsq,
-                       max_norm=self.grad_clip or 0.0, wd=self.weight_decay, guard=acc[0:1], skipped=self.skipped)
+        ops.adamw_step(eng.lora_p, eng.lora_g, self.m, self.v, 0.0, 0, sumsq=self.sumsq, max_norm=self.grad_clip or 0.0, wd=self.weight_decay,
+                       guard=eng.acc[0:1], skipped=self.skipped, state=self.state)
         eng.pack_lora()
-        return acc[0] / acc[1]
+        torch.div(eng.acc[0], eng.acc[1], out=self._loss_buf)
+
+    def _eager_step(self, audio, video, labels, prompt):
+        eng = self.model.llm_engine
+        self._part_fwd(audio, video, labels, prompt)
+        self.reducer.reduce_counts(eng.acc)
+        if self.reducer.enabled:      # eager: one bucket per decoder layer, launched from the C callback as that layer's kernels are enqueued
+            saved, self.bwd_pieces = self.bwd_pieces, 1
+            try:
+                self._part_bwd(0, per_layer_cb=self.reducer.layer_done)
+            finally:
+                self.bwd_pieces = saved
+        else:
+            for i in range(self.bwd_pieces):
+                self._part_bwd(i)
+        self.reducer.finish()
+        self._part_opt()
+
+    def _capture(self, audio, video, labels, prompt):
+        """Capture the step for this input signature.  Static input buffers are allocated here (the caller's tensors are copied into
+        them before every replay -- or ARE them, see static_inputs())."""
+        dev = self.model.llm_engine.lora_p.device
+        st = {"inputs": [None if t is None else torch.empty(t.shape, dtype=t.dtype, device=dev) for t in (audio, video, labels, prompt)]}
+        for dst, src in zip(st["inputs"], (audio, video, labels, prompt)):
+            if dst is not None:
+                dst.copy_(src)
+        pool = torch.cuda.graph_pool_handle()
+        a, v, lab, pr = st["inputs"]
+        torch.cuda.synchronize()
+        if not self.reducer.enabled:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._part_fwd(a, v, lab, pr)
+                for i in range(self.bwd_pieces):
+                    self._part_bwd(i)
+                self._part_opt()
+            st["all"] = g
+        else:
+            st["fwd"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["fwd"], pool=pool):
+                self._part_fwd(a, v, lab, pr)
+            st["bwd"] = []
+            for i in range(self.bwd_pieces):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self._part_bwd(i)
+                st["bwd"].append(g)
+            st["opt"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["opt"], pool=pool):
+                self._part_opt()
+        return st
+
+    def _replay(self, st):
+        if "all" in st:
+            st["all"].replay()
+            return
+        eng = self.model.llm_engine
+        st["fwd"].replay()
+        self.reducer.reduce_counts(eng.acc)
+        for i, g in enumerate(st["bwd"]):
+            g.replay()
+            hi, lo = self._piece_range(i)
+            self.reducer.layers_done(lo, hi)
+        self.reducer.finish()
+        st["opt"].replay()
+
+    def static_inputs(self, audio, video, labels, prompt):
+        """The device buffers a captured step reads for inputs of this signature (None before it has been captured).  A feeder that
+        writes its batches straight into them (H2D or a device-side producer) saves the per-step copy."""
+        st = self._graphs.get(self._signature(audio, video, labels, prompt))
+        return st["inputs"] if isinstance(st, dict) else None
+
+    @staticmethod
+    def _signature(*tensors):
+        return tuple(None if t is None else (tuple(t.shape), t.dtype) for t in tensors)
+
+    def train_step(self, audio, video, labels, prompt, graph=None):
+        """One optimizer step on this rank's batch; returns the (global) mean loss as a device scalar.
+        graph=False forces the eager launch sequence for this call (bench.py's instrumented steps)."""
+        use_graph = self.use_graph if graph is None else (graph and self.use_graph)
+        self.global_step += 1
+        if isinstance(labels, list):
+            labels = self.model._prep_labels(labels).cpu()
+        st = None
+        if use_graph:
+            key = self._signature(audio, video, labels, prompt)
+            st = self._graphs.get(key)
+            if st is None and len(self._graphs) < 4:
+                self._graphs[key] = st = "warm"          # first sight of a signature: eager (sizes every workspace); captured at the second
+            elif st == "warm":
+                self._graphs[key] = st = self._capture(audio, video, labels, prompt)
+        if isinstance(st, dict):
+            for dst, src in zip(st["inputs"], (audio, video, labels, prompt)):
+                if dst is not None and src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            self._replay(st)
+        else:
+            self._eager_step(audio, video, labels, prompt)
+        return self._loss_buf.clone()
 
     @property
     def skipped_steps(self):
@@ -181,6 +315,7 @@ class ClipWhisperTrainer:
         o = ck.get("optimizer_state_dict") or {}
         if "m" in o:
             self.m.copy_(o["m"]); self.v.copy_(o["v"]); self.global_step = int(o.get("step", 0))
+            self.state.view(torch.int32)[0] = self.global_step          # the device-side step count drives lr / bias corrections / seeds
         self.train_losses, self.val_losses = ck.get("train_losses", []), ck.get("val_losses", [])
         self.best_val_loss = ck.get("best_val_loss", float("inf"))
         return ck.get("epoch", 0)

@@ -61,9 +61,11 @@ int avllm_fuse_pool(const void* a, int32_t Ta, const void* v, int32_t Tv, const 
                     int32_t S_out, int32_t D, float fs, int32_t dtype, void* stream) { return av_fuse_pool(a, Ta, v, Tv, pe, P, out, B, L, S_out, D, fs, dtype, ST); }
 int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream) { return av_grad_sumsq(g, n, sumsq, ST); }
 int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                     int32_t step, const float* sumsq, float max_norm, float prescale, const float* guard, float* skipped, void* stream) {
-    return av_adamw_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, sumsq, max_norm, prescale, guard, skipped, ST);
+                     int32_t step, const float* sumsq, float max_norm, float prescale, const float* guard, float* skipped,
+                     const avllm_step_state* state, void* stream) {
+    return av_adamw_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, sumsq, max_norm, prescale, guard, skipped, state, ST);
 }
+int avllm_step_advance(avllm_step_state* state, const avllm_schedule* sched, void* stream) { return av_step_advance(state, sched, ST); }
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad, int64_t ld_at,
                     void* B_pad, void* BT_pad, int32_t dtype, void* stream) { return av_lora_pack(A, Bm, r, din, dout, A_pad, AT_pad, ld_at, B_pad, BT_pad, dtype, ST); }
 }

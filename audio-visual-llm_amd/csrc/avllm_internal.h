@@ -5,7 +5,7 @@
 
 int av_gemm(const avllm_gemm_desc* d, hipStream_t st);
 int av_gemm_tn(const void* P, long ldp, int I, const void* Q, long ldq, int J, int M, float* out, long ldo,
-               float alpha, int dtype, hipStream_t st, uint32_t drop_seed = 0, float drop_p = 0.f);
+               float alpha, int dtype, hipStream_t st, uint32_t drop_seed = 0, float drop_p = 0.f, const uint32_t* seed_dev = nullptr);
 int av_layernorm(const void* x, const void* w, const void* b, void* y, long rows, int d, float eps, int dtype, hipStream_t st);
 int av_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int d, float eps, int dtype, hipStream_t st);
 int av_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres_in, void* dx_out,
@@ -38,7 +38,7 @@ int av_fuse_pool(const void* a, int Ta, const void* v, int Tv, const void* promp
 int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st);
 int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const float* sumsq, float max_norm, float grad_prescale, const float* guard, float* skipped,
-                  hipStream_t st);
+                  const avllm_step_state* state, hipStream_t st);
 int av_lora_pack(const float* A, const float* Bm, int r, int din, int dout, void* A_pad, void* AT_pad, long ld_at,
                  void* B_pad, void* BT_pad, int dtype, hipStream_t st);
 int av_kv_append(const void* k, const void* v, long ld, void* kc, void* vc, int B, int T, int pos0, int Tmax, int d,
@@ -47,4 +47,5 @@ int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st, int G = 1);
 int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st);
 int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);
-int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st);
+int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st, const uint32_t* seed_dev = nullptr);
+int av_step_advance(avllm_step_state* state, const avllm_schedule* sched, hipStream_t st);

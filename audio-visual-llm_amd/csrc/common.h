@@ -167,6 +167,9 @@ __host__ __device__ __forceinline__ bool av_keep(uint32_t seed, unsigned long lo
     const uint32_t h = av_pair_hash(seed, idx >> 1);
     return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= av_drop_thr(p);
 }
+// The seed of a launch = (*seed_dev, when the caller keeps the step's base seed in device memory) + by-value offset.  A step whose
+// kernels take every per-step scalar from device memory is the same launch sequence every time, i.e. it can be replayed from a hipGraph.
+__device__ __forceinline__ uint32_t av_seed(const uint32_t* seed_dev, uint32_t off) { return (seed_dev ? *seed_dev : 0u) + off; }
 // mask 8 consecutive elements starting at an EVEN index (4 hashes)
 __device__ __forceinline__ void av_mask8(float (&v)[8], uint32_t seed, unsigned long long idx0, uint32_t thr, float sc) {
 #pragma unroll

@@ -111,7 +111,8 @@ __global__ void swiglu_bwd_kernel(const T* __restrict__ dh, const T* __restrict_
 
 // ---------------------------------------------------------------- dropout (counter-based mask, common.h av_keep)
 template <typename T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int d, uint32_t seed, float p) {
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int d, uint32_t seed_off, float p, const uint32_t* seed_dev) {
+    const uint32_t seed = av_seed(seed_dev, seed_off);
     const long total = rows * (d >> 2);
     const float sc = av_drop_scale(p);
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -395,11 +396,11 @@ int av_swiglu_bwd(const void* dh, const void* gu, void* dgu, long M, int F, int 
     return AV_OK;
 }
 
-int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st) {
+int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st, const uint32_t* seed_dev) {
     AV_CHECK_ARG(x && y && rows > 0 && d % 4 == 0 && p >= 0.f && p < 1.f, "dropout: bad args");
     const long total = rows * (d / 4);
-    if (dtype == AV_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)y, rows, d, seed, p);
-    else hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, rows, d, seed, p);
+    if (dtype == AV_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)y, rows, d, seed, p, seed_dev);
+    else hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, rows, d, seed, p, seed_dev);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -181,13 +181,14 @@ inline int llama_wid(const avllm_llama* m, int j) { return j == 0 ? m->d : llama
 int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long ldw, int K, int N, const avllm_lora_mod& lm,
               void* t, long ldt, void* y, long ldy, const void* R, long ldr, int M, hipStream_t st, const void* xl = nullptr,
               uint32_t a_seed = 0, float a_p = 0.f) {
+    // (the step's base seed may live in device memory: m->dropout_seed_dev, see avllm_step_state)
     avllm_gemm_desc g;
     const bool has = lm.A_pad != nullptr;
     if (has) {
         // xl = dropout(x) for the adapter branch when lora_dropout is active (peft: lora_B(lora_A(dropout(x))))
         g = gemm_desc(m->dtype, xl ? xl : x, xl ? (long)K : ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
         g.alpha = m->lora_scale;
-        g.a_drop_seed = a_seed; g.a_drop_p = a_p;      // bf16: dropout generated inside the rank-side GEMM
+        g.a_drop_seed = a_seed; g.a_drop_p = a_p; g.seed_dev = m->dropout_seed_dev;      // bf16: dropout generated inside the rank-side GEMM
         g.n_valid = m->lora_r;                         // rank padded to 64: the padding columns are written as zeros, not computed
         AV_TRY(av_gemm(&g, st));
     }
@@ -302,7 +303,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
         for (int j = 0; j < 3; ++j) {
             const void* xl = nullptr;
             const uint32_t sj = m->dropout_seed + 4u * l + j;
-            if (drop && !fuse_drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, sj, m->lora_dropout, dt, st)); xl = w.xd; }
+            if (drop && !fuse_drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, sj, m->lora_dropout, dt, st, m->dropout_seed_dev)); xl = w.xd; }
             AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)llama_off(m, j) * d * es, d, d, llama_wid(m, j), P.lora[j],
                              (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
                              (char*)a.qkv + (size_t)llama_off(m, j) * es, qw, nullptr, 0, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
@@ -314,7 +315,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
         {
             const void* xl = nullptr;
             const uint32_t so = m->dropout_seed + 4u * l + 3;
-            if (drop && !fuse_drop && P.lora[3].A_pad) { AV_TRY(av_dropout(a.att, w.xd, M, d, so, m->lora_dropout, dt, st)); xl = w.xd; }
+            if (drop && !fuse_drop && P.lora[3].A_pad) { AV_TRY(av_dropout(a.att, w.xd, M, d, so, m->lora_dropout, dt, st, m->dropout_seed_dev)); xl = w.xd; }
             AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st, xl, so,
                              fuse_drop ? m->lora_dropout : 0.f));
         }
@@ -337,8 +338,16 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
 extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels, int32_t B, int32_t S, const float* count,
                                     float grad_scale, void* ws, size_t ws_bytes, avllm_layer_cb after_layer, void* user,
                                     void* stream) {
+    AV_TRY(check_llama(m));
+    return avllm_llama_lora_bwd_layers(m, labels, B, S, count, grad_scale, ws, ws_bytes, m->layers - 1, 0, after_layer, user, stream);
+}
+
+extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* labels, int32_t B, int32_t S, const float* count,
+                                           float grad_scale, void* ws, size_t ws_bytes, int32_t layer_hi, int32_t layer_lo,
+                                           avllm_layer_cb after_layer, void* user, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AV_TRY(check_llama(m));
+    AV_CHECK_ARG(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi < m->layers, "llama_lora_bwd_layers: bad layer range [%d, %d]", layer_lo, layer_hi);
     AV_CHECK_ARG(labels && count && ws && m->lm_head_t, "llama_lora_bwd: null (training needs the transposed weight images)");
     Bump b(ws, ws_bytes);
     LlamaTrainWs w;
@@ -353,12 +362,15 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
     const bool drop = m->lora_dropout > 0.f;
     // bf16 (MFMA kernels): masks are generated inside the rank-side GEMMs; fp32 parity mode materialises dropout(x)
     const bool fuse_drop = drop && m->dtype == AV_BF16 && d % 256 == 0 && m->lora_r <= 16;
-    AV_TRY(av_ce_bwd(w.logits, V, labels, w.row_lse, count, grad_scale, w.logits, B, S, V, dt, st));
-    avllm_gemm_desc g = gemm_desc(dt, w.logits, V, m->lm_head_t, V, w.dxn, d, M, d, V);
-    AV_CHECK_ARG(V % 64 == 0, "llama_lora_bwd: vocab %d must be a multiple of 64", V);
-    AV_TRY(av_gemm(&g, st));
-    AV_TRY(av_rmsnorm_bwd(w.dxn, resid[m->layers], m->norm_w, w.rstd_f, nullptr, w.dres, M, d, dt, st));
-    for (int l = m->layers - 1; l >= 0; --l) {
+    avllm_gemm_desc g;
+    if (layer_hi == m->layers - 1) {      // the piece that starts at the top also runs loss -> lm_head -> final norm
+        AV_TRY(av_ce_bwd(w.logits, V, labels, w.row_lse, count, grad_scale, w.logits, B, S, V, dt, st));
+        g = gemm_desc(dt, w.logits, V, m->lm_head_t, V, w.dxn, d, M, d, V);
+        AV_CHECK_ARG(V % 64 == 0, "llama_lora_bwd: vocab %d must be a multiple of 64", V);
+        AV_TRY(av_gemm(&g, st));
+        AV_TRY(av_rmsnorm_bwd(w.dxn, resid[m->layers], m->norm_w, w.rstd_f, nullptr, w.dres, M, d, dt, st));
+    }
+    for (int l = layer_hi; l >= layer_lo; --l) {
         const avllm_llama_layer& P = m->layer[l];
         LlamaLayerAct& a = act[l];
         AV_CHECK_ARG(P.wqkv_t && P.wo_t && P.wgu_t && P.wdown_t, "llama_lora_bwd: layer %d has no transposed weights", l);
@@ -378,15 +390,15 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             gt.alpha = sc; gt.n_valid = R;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.att;
-            if (drop && !fuse_drop) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st)); xin = w.xd; }
+            if (drop && !fuse_drop) { AV_TRY(av_dropout(a.att, w.xd, M, d, m->dropout_seed + 4u * l + 3, m->lora_dropout, dt, st, m->dropout_seed_dev)); xin = w.xd; }
             AV_TRY(av_gemm_tn(w.dto, AVLLM_LORA_PAD, R, xin, d, d, M, lo.gA, d, 1.0f, dt, st, m->dropout_seed + 4u * l + 3,
-                              fuse_drop ? m->lora_dropout : 0.f));
+                              fuse_drop ? m->lora_dropout : 0.f, m->dropout_seed_dev));
             if (!drop) { g.A2 = w.dto; g.lda2 = AVLLM_LORA_PAD; g.B2 = lo.AT_pad; g.ldb2 = lo.ld_at; g.K2 = AVLLM_LORA_PAD; }
         }
         AV_TRY(av_gemm(&g, st));
         if (lo.A_pad && drop) {       // d att += mask_o * (dto . A_o) / (1-p): the adapter's input gradient passes back through its dropout
             avllm_gemm_desc gm = gemm_desc(dt, w.dto, AVLLM_LORA_PAD, lo.AT_pad, lo.ld_at, w.datt, d, M, d, AVLLM_LORA_PAD);
-            gm.R = w.datt; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + 3; gm.drop_p = m->lora_dropout;
+            gm.R = w.datt; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + 3; gm.drop_p = m->lora_dropout; gm.seed_dev = m->dropout_seed_dev;
             AV_TRY(av_gemm(&gm, st));
         }
         // ---- attention
@@ -411,9 +423,9 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
             gt.alpha = sc; gt.n_valid = R;
             AV_TRY(av_gemm(&gt, st));
             const void* xin = a.xn1;
-            if (drop && !fuse_drop) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st)); xin = w.xd; }
+            if (drop && !fuse_drop) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, m->dropout_seed + 4u * l + j, m->lora_dropout, dt, st, m->dropout_seed_dev)); xin = w.xd; }
             AV_TRY(av_gemm_tn(dtj, 3 * AVLLM_LORA_PAD, R, xin, d, d, M, lj.gA, d, 1.0f, dt, st, m->dropout_seed + 4u * l + j,
-                              fuse_drop ? m->lora_dropout : 0.f));
+                              fuse_drop ? m->lora_dropout : 0.f, m->dropout_seed_dev));
             if (lj.ld_at != 3 * AVLLM_LORA_PAD ||
                 (const char*)lj.AT_pad != (const char*)P.lora[0].AT_pad + (size_t)j * AVLLM_LORA_PAD * es) contiguous = false;
         }
@@ -428,7 +440,7 @@ extern "C" int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels,
                     if (!lj.A_pad) continue;
                     avllm_gemm_desc gm = gemm_desc(dt, (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD, lj.AT_pad, lj.ld_at,
                                                    w.dxn, d, M, d, AVLLM_LORA_PAD);
-                    gm.R = w.dxn; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + j; gm.drop_p = m->lora_dropout;
+                    gm.R = w.dxn; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + j; gm.drop_p = m->lora_dropout; gm.seed_dev = m->dropout_seed_dev;
                     AV_TRY(av_gemm(&gm, st));
                 }
             }

@@ -29,7 +29,7 @@ struct EpiParams {
     int g_in, g_out, g_off;
     float alpha; int act;
     int M, N;
-    uint32_t drop_seed; float drop_p;
+    uint32_t drop_seed; float drop_p; const uint32_t* seed_dev;
 };
 
 // v[4] = 4 consecutive output columns n0..n0+3 of logical row m
@@ -47,7 +47,7 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& e, int m, int n
     if (e.drop_p > 0.f) {
         const float sc = av_drop_scale(e.drop_p);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = av_keep(e.drop_seed, (unsigned long long)m * e.N + n0 + i, e.drop_p) ? v[i] * sc : 0.f;
+        for (int i = 0; i < 4; ++i) v[i] = av_keep(av_seed(e.seed_dev, e.drop_seed), (unsigned long long)m * e.N + n0 + i, e.drop_p) ? v[i] * sc : 0.f;
     }
     if (e.R) {
         const long rr = e.r_mod > 0 ? (m % e.r_mod) : m;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n
         for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], e.act);
     }
     if (e.drop_p > 0.f) {
-        av_mask8(v, e.drop_seed, (unsigned long long)m * e.N + n0, av_drop_thr(e.drop_p), av_drop_scale(e.drop_p));      // N % 8 == 0: even start
+        av_mask8(v, av_seed(e.seed_dev, e.drop_seed), (unsigned long long)m * e.N + n0, av_drop_thr(e.drop_p), av_drop_scale(e.drop_p));      // N % 8 == 0: even start
     }
     if (e.R) {
         const long rr = e.r_mod > 0 ? (m % e.r_mod) : m;
@@ -1004,8 +1004,9 @@ __device__ __forceinline__ bf16x8 drop_frag(bf16x8 x, uint32_t seed, unsigned lo
 template <bool DROP, int NV>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny64_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B,
                                                                       long ldb, int M, int K, float alpha, void* __restrict__ C, long ldc,
-                                                                      int out_f32, uint32_t seed, float p) {
+                                                                      int out_f32, uint32_t seed_off, float p, const uint32_t* seed_dev) {
     __shared__ float part[SK_WAVES][16][NV * 16 + 1];
+    const uint32_t seed = DROP ? av_seed(seed_dev, seed_off) : 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.x * 16;
@@ -1208,7 +1209,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     e.C = d->C; e.ldc = d->ldc; e.out_f32 = d->out_f32 || d->dtype == AV_F32; e.bias = d->bias; e.R = d->R; e.ldr = d->ldr;
     e.r_mod = d->r_mod; e.g_in = d->g_in; e.g_out = d->g_out; e.g_off = d->g_off;
     e.alpha = d->alpha; e.act = d->act; e.M = d->M; e.N = d->N;
-    e.drop_seed = d->drop_seed; e.drop_p = d->drop_p;
+    e.drop_seed = d->drop_seed; e.drop_p = d->drop_p; e.seed_dev = d->seed_dev;
     const bool prof = av_prof_enabled();
     if (prof) av_prof_before(st);
     const size_t osz = e.out_f32 ? 4 : 2;
@@ -1228,7 +1229,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         AV_CHECK_ARG(d->n_valid >= 0 && d->n_valid <= 64, "gemm: n_valid=%d", d->n_valid);
         const int nv = d->n_valid > 0 ? (d->n_valid + 15) / 16 : 4;
 #define AV_SKINNY(DROPV, NVV, SEED, P) hipLaunchKernelGGL((gemm_skinny64_kernel<DROPV, NVV>), dim3(av_cdiv(d->M, 16)), dim3(SK_WAVES * 64), 0, st, \
-            (const bf16*)d->A, d->lda, (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, SEED, P)
+            (const bf16*)d->A, d->lda, (const bf16*)d->B, d->ldb, d->M, d->K, d->alpha, d->C, d->ldc, e.out_f32, SEED, P, d->seed_dev)
         if (d->a_drop_p > 0.f) {
             if (nv == 1) AV_SKINNY(true, 1, d->a_drop_seed, d->a_drop_p);
             else if (nv == 2) AV_SKINNY(true, 2, d->a_drop_seed, d->a_drop_p);

@@ -29,11 +29,12 @@ constexpr int SM_STRIDE = 48;                 // 16 bf16 + pad
 template <bool TRANS_OUT>
 __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restrict__ Big, long ldb, const bf16* __restrict__ Small,
                                                            long lds_, int R, int M, int mchunk, float* __restrict__ out, long ldo,
-                                                           float alpha, int NB, uint32_t drop_seed, float drop_p) {
+                                                           float alpha, int NB, uint32_t drop_seed_off, float drop_p, const uint32_t* seed_dev) {
     __shared__ __attribute__((aligned(16))) char big_s[TN_M * BIG_STRIDE];
     __shared__ __attribute__((aligned(16))) char small_s[TN_M * SM_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n0 = blockIdx.x * TN_N;
+    const uint32_t drop_seed = drop_p > 0.f ? av_seed(seed_dev, drop_seed_off) : 0u;
     const int m_begin = blockIdx.y * mchunk, m_end = min(M, m_begin + mchunk);
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
 
 // Big [M,NB] (NB % 128 == 0), Small [M,>=16 cols, R valid]; out [NB,R] (TRANS_OUT=0) or [R,NB] (TRANS_OUT=1)
 int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
-                    int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p) {
+                    int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p, const uint32_t* seed_dev) {
     // token chunks: enough workgroups to fill the chip (NB/128 x zs >= 256) but as few atomic adders per element as that allows
     static const int chunk_env = getenv("AVLLM_TN_CHUNK") ? atoi(getenv("AVLLM_TN_CHUNK")) : 0;
     // [NB,R] output = 64-byte rows scattered across lanes (slow atomics): fewer, longer chunks (measured 13.8 vs 18.3 us at 512 vs 256)
@@ -117,8 +118,8 @@ int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long l
     mchunk = (mchunk + TN_M - 1) / TN_M * TN_M;
     zs = av_cdiv(M, mchunk);
     const dim3 grid(NB / TN_N, zs);
-    if (trans_out) hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha, NB, drop_seed, drop_p);
-    else hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha, NB, drop_seed, drop_p);
+    if (trans_out) hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha, NB, drop_seed, drop_p, seed_dev);
+    else hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), grid, dim3(256), 0, st, (const bf16*)Big, ldb, (const bf16*)Small, lds_, R, M, mchunk, out, ldo, alpha, NB, drop_seed, drop_p, seed_dev);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -5,7 +5,7 @@
 #include "avllm_internal.h"
 
 int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
-                    int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p);
+                    int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p, const uint32_t* seed_dev);
 
 namespace {
 
@@ -119,12 +119,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                              const float* __restrict__ sumsq, float max_norm, float prescale, const float* __restrict__ guard,
-                             float* __restrict__ skipped) {
+                             float* __restrict__ skipped, avllm_step_state* __restrict__ state) {
+    if (state) { lr = state->lr; bc1 = state->bc1; bc2_sqrt = state->bc2_sqrt; }     // graph-replayable step: per-step scalars live on the device
     // Non-finite step guard (trainer/clip_whisper_trainer.py:444-452 skips backward and the optimizer on a NaN/Inf loss): decided on the
     // device from values every thread reads alike, so the step costs no host sync and p, m, v stay untouched when it is skipped.
     const bool bad = (sumsq && !isfinite(sumsq[0])) || (guard && !isfinite(guard[0]));
     if (bad) {
-        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1.0f);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (skipped) atomicAdd(skipped, 1.0f);
+            if (state) atomicAdd(&state->skipped, 1.0f);
+        }
         return;
     }
     float coef = prescale;
@@ -223,23 +227,52 @@ int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st) {
 
 int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const float* sumsq, float max_norm, float grad_prescale, const float* guard, float* skipped,
-                  hipStream_t st) {
-    AV_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+                  const avllm_step_state* state, hipStream_t st) {
+    AV_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || state), "adamw: bad args");
+    if (step < 1) step = 1;
     const float bc1 = 1.0f - (float)pow((double)b1, step);
     const float bc2s = (float)sqrt(1.0 - pow((double)b2, step));
     long blocks = (n + 255) / 256;
     blocks = blocks > 4096 ? 4096 : blocks;
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, sumsq, max_norm, grad_prescale, guard, skipped);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, sumsq, max_norm, grad_prescale, guard, skipped, (avllm_step_state*)state);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+// One thread advances the step's device-side scalars (include/avllm.h avllm_step_state): the host-side bookkeeping of
+// trainer/clip_whisper_trainer.py:461-464 (optimizer step count, scheduler.step()) and the step's dropout seed.
+__global__ void step_advance_kernel(avllm_step_state* s, avllm_schedule c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t step = s->step + 1;
+    const float t = (float)(step - 1), total = (float)(c.total_steps > 0 ? c.total_steps : 1);
+    float lr;
+    if (c.warmup_steps > 0) {
+        const float w = (float)c.warmup_steps;
+        if (t < w) lr = c.base_lr * t / w;
+        else lr = c.base_lr * fmaxf(0.f, 0.5f * (1.0f + cosf(3.14159265358979323846f * (t - w) / fmaxf(1.f, total - w))));
+    } else {
+        lr = c.base_lr * (1.0f + cosf(3.14159265358979323846f * t / total)) * 0.5f;
+    }
+    s->step = step;
+    s->lr = lr;
+    s->bc1 = 1.0f - powf(c.beta1, (float)step);
+    s->bc2_sqrt = sqrtf(1.0f - powf(c.beta2, (float)step));
+    s->dropout_seed = step * 0x9E3779B1u + c.rank * 0x85EBCA6Bu + 12345u;
+}
+
+int av_step_advance(avllm_step_state* state, const avllm_schedule* sched, hipStream_t st) {
+    AV_CHECK_ARG(state && sched, "step_advance: null");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, state, *sched);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
 
 int av_gemm_tn(const void* P, long ldp, int I, const void* Q, long ldq, int J, int M, float* out, long ldo,
-               float alpha, int dtype, hipStream_t st, uint32_t drop_seed, float drop_p) {
+               float alpha, int dtype, hipStream_t st, uint32_t drop_seed, float drop_p, const uint32_t* seed_dev) {
     AV_CHECK_ARG(P && Q && out && I > 0 && J > 0 && M > 0, "gemm_tn: bad args");
     if (dtype == AV_BF16 && ldp % 8 == 0 && ldq % 8 == 0) {
-        if (J <= 16 && I % 128 == 0) return av_gemm_tn_mfma(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, 0, st, drop_seed, drop_p);
-        if (I <= 16 && J % 128 == 0) return av_gemm_tn_mfma(Q, ldq, J, P, ldp, I, M, out, ldo, alpha, 1, st, drop_seed, drop_p);
+        if (J <= 16 && I % 128 == 0) return av_gemm_tn_mfma(P, ldp, I, Q, ldq, J, M, out, ldo, alpha, 0, st, drop_seed, drop_p, seed_dev);
+        if (I <= 16 && J % 128 == 0) return av_gemm_tn_mfma(Q, ldq, J, P, ldp, I, M, out, ldo, alpha, 1, st, drop_seed, drop_p, seed_dev);
     }
     if (drop_p > 0.f) return av_set_error(AV_ERR_UNSUPPORTED, "gemm_tn: on-the-fly dropout needs the bf16 MFMA path (rank <= 16, width %% 128 == 0)");
     int zs = av_cdiv(M, 256);

@@ -56,6 +56,7 @@ typedef struct avllm_gemm_desc {
     float a_drop_p;                     /*   peft's lora_A(dropout(x)) without materialising dropout(x) */
     int32_t n_valid;                    /* N == 64 rank-side GEMM: only rows [0,n_valid) of B are non-zero (rank padded to 64); the other
                                          * output columns are written as zeros without being computed.  0 = all N */
+    const uint32_t* seed_dev;           /* optional DEVICE word added to drop_seed / a_drop_seed at run time (see avllm_step_state) */
 } avllm_gemm_desc;
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
 /* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT) */
@@ -67,6 +68,28 @@ int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t 
 /* same, with dropout(seed,p) applied on the fly to the WIDE operand (mask index m*width+col; bf16 MFMA path only) */
 int avllm_gemm_tn_drop(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
                        float* out, int64_t ldo, float alpha, uint32_t drop_seed, float drop_p, int32_t dtype, void* stream);
+
+/* Per-step scalars kept in DEVICE memory so that a training step is the same launch sequence every time and can be captured in a
+ * hipGraph (trainer/clip_whisper_trainer.py:433-490 recomputes them on the host each step: scheduler.step() :464, the optimizer's
+ * step count, torch's dropout RNG).  avllm_step_advance is a one-thread kernel: step += 1, then
+ *   lr           = cosine schedule of _setup_optimizer :210-230 at (step-1): base_lr*(1+cos(pi*s/total))/2, or linear warm-up over
+ *                  warmup_steps followed by the cosine over the remaining steps (transformers get_cosine_schedule_with_warmup)
+ *   bc1, bc2_sqrt = 1-beta1^step, sqrt(1-beta2^step)                           (torch.optim.AdamW bias corrections)
+ *   dropout_seed = step*0x9E3779B1 + rank*0x85EBCA6B + 12345                   (this step's LoRA dropout mask seed)
+ * Consumers: avllm_llama.dropout_seed_dev (-> &state->dropout_seed), avllm_adamw_step(state). */
+typedef struct avllm_step_state {
+    uint32_t step;                      /* optimizer steps started (1-based after the first advance) */
+    uint32_t dropout_seed;
+    float lr, bc1, bc2_sqrt;
+    float skipped;                      /* steps whose update was skipped by the non-finite guard (see avllm_adamw_step) */
+    uint32_t reserved[2];
+} avllm_step_state;
+typedef struct avllm_schedule {
+    float base_lr, beta1, beta2;
+    int32_t warmup_steps, total_steps;
+    uint32_t rank;
+} avllm_schedule;
+int avllm_step_advance(avllm_step_state* state_dev, const avllm_schedule* sched, void* stream);
 
 /* nn.LayerNorm (HF whisper :379-413, clip :362-384) */
 int avllm_layernorm(const void* x, const void* w, const void* b, void* y, int64_t rows, int32_t d, float eps,
@@ -138,7 +161,9 @@ int avllm_fuse_pool(const void* a, int32_t Ta, const void* v, int32_t Tv, const 
 int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
 int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t step, const float* sumsq, float max_norm,
-                     float grad_prescale, const float* guard, float* skipped, void* stream);
+                     float grad_prescale, const float* guard, float* skipped, const avllm_step_state* state_dev, void* stream);
+/* state_dev != NULL: lr and the bias corrections come from *state_dev (the `lr` and `step` arguments are ignored) and skipped steps
+ * are also counted in state_dev->skipped. */
 /* build the four padded operand images of one LoRA pair from the fp32 masters A [r,din], B [dout,r]:
  * A_pad [64,din], AT_pad [din,64] (row stride ld_at), B_pad [dout,64], BT_pad [64,dout] in `dtype` */
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,
@@ -252,6 +277,7 @@ typedef struct avllm_llama {
     float eps, theta, lora_scale;
     float lora_dropout;              /* applied by avllm_llama_lora_fwd_loss/_bwd only (training); 0 = off */
     uint32_t dropout_seed;           /* module j of layer l uses seed dropout_seed + 4*l + j; change it every step */
+    const uint32_t* dropout_seed_dev;/* optional DEVICE word added to dropout_seed at run time (graph-replayable steps: avllm_step_state) */
     const void* embed;               /* [vocab,d] */
     const void* norm_w;
     const void* lm_head;             /* [vocab,d] */
@@ -275,6 +301,13 @@ typedef void (*avllm_layer_cb)(int32_t layer, void* user);
 int avllm_llama_lora_bwd(const avllm_llama* m, const int64_t* labels, int32_t B, int32_t S, const float* count,
                          float grad_scale, void* ws, size_t ws_bytes, avllm_layer_cb after_layer, void* user,
                          void* stream);
+/* The same backward pass in pieces: decoder layers layer_hi, layer_hi-1, ..., layer_lo (inclusive).  The piece that starts at the
+ * last layer (layer_hi == layers-1) also runs the loss / lm_head / final-norm part; consecutive pieces must be called in descending
+ * order on the same ws (the running residual gradient stays there).  Lets a data-parallel caller replay each piece from its own
+ * hipGraph and launch that piece's gradient all-reduce while the next piece runs. */
+int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* labels, int32_t B, int32_t S, const float* count,
+                                float grad_scale, void* ws, size_t ws_bytes, int32_t layer_hi, int32_t layer_lo,
+                                avllm_layer_cb after_layer, void* user, void* stream);
 
 /* Inference: prefill on inputs_embeds and single-token steps with a KV cache (llm.generate,
  * clip_whisper_model.py:1337-1340 -> GenerationMixin greedy).  kcache/vcache [layers][B][Tmax][d].

@@ -70,20 +70,23 @@ def test_two_ranks_equal_one_process(dev):
 
 def _rccl_worker(port, q):
     """world_size 1 over the `nccl` backend (= RCCL): the code bench.py / train.py run on the 8-GPU node -- init with device_id,
-    the token-count all-reduce on the compute stream, 32-bucket-style async all-reduces on the side stream from the C callback,
-    work.wait() + stream join before the optimizer -- executes for real, on the one GPU this box has."""
+    the token-count all-reduce on the compute stream, async gradient all-reduces on the side stream (per decoder layer from the C
+    callback in the eager step; per backward piece between hipGraph replays in the captured step), work.wait() + stream join before
+    the optimizer -- executes for real, on the one GPU this box has."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     m, tr, audio, video, labels, prompt = _build("cuda:0")
     assert not tr.reducer.enabled                       # world_size 1 is not "distributed" ...
     tr.reducer.enabled = True                           # ... so the reducer is forced on: every collective of the N > 1 path is issued
+    tr.bwd_pieces = 2                                   # and the data-parallel graph layout: forward | 2 backward pieces | optimizer
     calls = []
-    orig = tr.reducer.layer_done
-    tr.reducer.layer_done = lambda layer: (calls.append(layer), orig(layer))[1]
-    losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(2)]
+    o1, o2 = tr.reducer.layer_done, tr.reducer.layers_done
+    tr.reducer.layer_done = lambda layer: (calls.append(("layer", layer)), o1(layer))[1]
+    tr.reducer.layers_done = lambda lo, hi: (calls.append(("piece", lo, hi)), o2(lo, hi))[1]
+    losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(3)]
     torch.cuda.synchronize()
-    q.put((losses, m.llm_engine.lora_p.cpu().numpy(), calls, dist.get_backend()))
+    q.put((losses, m.llm_engine.lora_p.cpu().numpy(), calls, dist.get_backend(), tr.use_graph))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -93,12 +96,13 @@ def test_rccl_backend_world_size_1_matches_non_distributed(dev):
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(31700 + os.getpid() % 2000, q))
     p.start()
-    losses, params, calls, backend = q.get(timeout=600)
+    losses, params, calls, backend, graphed = q.get(timeout=600)
     p.join(timeout=120)
-    assert p.exitcode == 0 and backend == "nccl"
-    assert calls == [1, 0, 1, 0]                        # one bucket per decoder layer, last layer first, both steps
+    assert p.exitcode == 0 and backend == "nccl" and graphed
+    # step 1 eager: one bucket per decoder layer, last layer first; steps 2 and 3 replay graphs: one bucket per backward piece
+    assert calls == [("layer", 1), ("layer", 0)] + 2 * [("piece", 1, 1), ("piece", 0, 0)], calls
     m, tr, audio, video, labels, prompt = _build("cuda:0")
-    ref_losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(2)]
+    ref_losses = [float(tr.train_step(audio.cuda(), video.cuda(), labels.cuda(), prompt.cuda())) for _ in range(3)]
     assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-4, (losses, ref_losses)
     ref = m.llm_engine.lora_p.cpu()
     init = _build("cuda:0")[0].llm_engine.lora_p.cpu()

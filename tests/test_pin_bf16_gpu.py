@@ -331,3 +331,41 @@ def test_backward_refuses_overwritten_activations(dev, golden_dir):
     m(**kw)                                                                       # a second TRAINING forward overwrites the activations
     with pytest.raises(RuntimeError, match="another training forward"):
         out["loss"].backward()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replayed_step_matches_eager_step(dev, golden_dir, precision):
+    """The captured step (hipGraph replay, per-step scalars in the device-side avllm_step_state) against the same step launched eagerly:
+    same losses, same parameters after 5 steps with LoRA dropout, gradient clipping, warm-up + cosine schedule -- i.e. the device-side
+    learning rate, Adam bias corrections and dropout seeds follow the host-side rule (trainer/clip_whisper_trainer.py:457-464)."""
+    import numpy as np
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    from avllm.trainer import ClipWhisperTrainer
+    g = np.load(f"{golden_dir}/g2_tiny_e2e.npz")
+    oc = Wt.tiny()
+    W = Wt.all_weights(oc, int(g["seed"]), lora_b_std=0.05)
+    audio, video, labels, prompt = Wt.synthetic_batch(oc, 2, 3, seed=3)
+    audio2, video2, labels2, prompt2 = Wt.synthetic_batch(oc, 2, 3, seed=4)
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    runs = {}
+    for graph in (False, True):
+        m = ClipWhisperModel(device="cuda:0", lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.1, max_seq_len=512, config=cfg,
+                             weights=W, precision=precision).train()
+        tr = ClipWhisperTrainer(m, learning_rate=1e-3, total_steps=8, max_epochs=1, warmup_steps=2, grad_clip=0.5, use_graph=graph)
+        losses = []
+        for s in range(5):
+            b = (audio, video, labels, prompt) if s % 2 == 0 else (audio2, video2, labels2, prompt2)      # same signature, new data
+            losses.append(float(tr.train_step(*[t.to(dev) for t in b])))
+        st = tr.state.cpu().numpy().view(np.uint32)
+        assert int(st[0]) == 5 and tr.global_step == 5
+        assert abs(float(tr.state.cpu().numpy().view(np.float32)[2]) - tr.lr_at(4)) < 1e-8       # device-side schedule == host-side rule
+        runs[graph] = (losses, m.llm_engine.lora_p.cpu().clone())
+        if graph:
+            assert any(isinstance(v, dict) for v in tr._graphs.values())                     # a graph really was captured and replayed
+    (l0, p0), (l1, p1) = runs[False], runs[True]
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < tol, (l0, l1)
+    init = torch.cat([W["lora"][k].flatten() for k in sorted(W["lora"])])
+    assert rel_l2(p1, p0) < (1e-4 if precision == "fp32" else 2e-2)
+    assert float((p0 - p1).abs().max()) < float((p0.abs().max())) * 0.05 and not torch.equal(p0, torch.zeros_like(p0)) and init.numel() == p0.numel()
