@@ -109,6 +109,8 @@ _SIGS = {
     "avllm_grad_sumsq": ([vp, i64, vp, vp], i32),
     "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp, vp], i32),
     "avllm_step_advance": ([vp, C.POINTER(Schedule), vp], i32),
+    "avllm_lora_dx_masked": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(C.c_uint32), i32, i32, vp, i64, vp, i64, i32,
+                              i32, f32, vp, i32, vp], i32),
     "avllm_llama_lora_bwd_layers": ([C.POINTER(Llama), vp, i32, i32, vp, f32, vp, sz, i32, i32, LAYER_CB, vp, vp], i32),
     "avllm_lora_pack": ([vp, vp, i32, i32, i32, vp, vp, i64, vp, vp, i32, vp], i32),
     "avllm_profile_begin": ([i32], i32),

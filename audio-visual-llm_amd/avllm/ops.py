@@ -197,6 +197,20 @@ def adamw_step(p, g, m, v, lr, step, sumsq=None, max_norm=0.0, beta1=0.9, beta2=
                                       L.ptr(sumsq), max_norm, prescale, L.ptr(guard), L.ptr(skipped), L.ptr(state), L.stream_ptr()))
 
 
+def lora_dx_masked(Ts, ATs, seeds, r, p, R=None, out=None, seed_dev=None):
+    """out = R + sum_j mask_j o (T_j . A_j)/(1-p): the adapters' input gradient under LoRA dropout in one pass (avllm_lora_dx_masked).
+    Ts[j] [M,>=32] (zeros past r), ATs[j] [N,>=32] padded transposed A images; out may be R."""
+    n = len(Ts)
+    M, N = Ts[0].shape[0], ATs[0].shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=Ts[0].device, dtype=Ts[0].dtype)
+    arr = lambda ty, vals: (ty * n)(*vals)
+    L.check(L.load().avllm_lora_dx_masked(arr(L.vp, [L.ptr(t) for t in Ts]), arr(L.i64, [_ld(t) for t in Ts]), arr(L.vp, [L.ptr(t) for t in ATs]),
+                                          arr(L.i64, [_ld(t) for t in ATs]), arr(C.c_uint32, [s & 0xFFFFFFFF for s in seeds]), n, r, L.ptr(R),
+                                          _ld(R) if R is not None else 0, L.ptr(out), _ld(out), M, N, p, seed_dev, L.dt_of(out), L.stream_ptr()))
+    return out
+
+
 def step_advance(state, base_lr, total_steps, warmup_steps=0, beta1=0.9, beta2=0.95, rank=0):
     """One-thread kernel: state.step += 1 and this step's lr / bias corrections / dropout seed (include/avllm.h avllm_step_state)."""
     sc = L.Schedule(base_lr, beta1, beta2, int(warmup_steps), int(total_steps), int(rank))

@@ -249,6 +249,165 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ short non-causal sequences (CLIP)
+// One workgroup = one (frame, head); the whole K and V of the head (<= 16 NKB keys) are staged once.  A wave takes 16 queries at a time
+// and keeps ALL their scores in registers (4 NKB fp32 per lane), so the softmax is two exact passes over registers -- no running max,
+// no rescale of the output accumulator, no alpha exponentials -- and every product is v_mfma_f32_16x16x32_bf16:
+//   S^T[key][query] = K . Q^T      A = K rows from LDS (ds_read_b128, 160-byte rows: conflict free), B = the wave's Q rows (registers)
+//   row max          over the lane's 4 NKB registers, then across the four lane groups that share a query (2 cross-lane steps)
+//   P = exp2(S * scale*log2e - max)                                                        (the only transcendental per score)
+//   l   += 1^T . P^T               the row SUM is one more MFMA with an all-ones A operand instead of 4 NKB VALU adds
+//   O^T += V^T . P^T               P's registers, converted pairwise to bf16, ARE the B operand (key order permuted inside a 32-key
+//                                  step: elements 0..3 = keys 4g..4g+3 of the first 16-key block, 4..7 = the same of the second);
+//                                  V^T fragments come from the row-major V image through ds_read_b64_tr_b16 in that same order.
+// 197 tokens (ViT-B/16) are 13 blocks of 16 in both directions (208 padded rows instead of the 224 of a 32-row tiling); 7 waves x 2
+// query blocks.  Output leaves through a 16x32 bf16 scratch per wave as 16-byte row chunks.  HF:models/clip/modeling_clip.py:297-335.
+template <int NKB, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                          bf16* __restrict__ o, float* __restrict__ lse, int T, int H, long ldq, long ldk,
+                                                          long ldv, long ldo, float scale_log2e, int G) {
+    constexpr int HD = 64, KS = 160, VS = 160, OS = 80;
+    constexpr int NPV = (NKB + 1) / 2, KROWS = NKB * 16, VROWS = NPV * 32, NT = NW * 64;
+    constexpr int NQ = (NKB + NW - 1) / NW;                       // query blocks per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* v_lds = smem + KROWS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    char* o_lds = smem + KROWS * KS + VROWS * VS + w * 16 * OS;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hh = blockIdx.x, b = blockIdx.y, hk = hh / G;
+    const int nkb = (T + 15) >> 4;
+
+    // ---- stage K (rows < KROWS) and V (rows < VROWS), zero past T; every global load is issued before the first LDS store
+    constexpr int NCH = (VROWS * 8 + NT - 1) / NT;
+    u32x4 kreg[NCH], vreg[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT, row = c >> 3, ch = c & 7;
+        kreg[i] = (u32x4){0u, 0u, 0u, 0u}; vreg[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (row < T) {
+            kreg[i] = *(const u32x4*)(k + ((long)b * T + row) * ldk + (long)hk * HD + ch * 8);
+            vreg[i] = *(const u32x4*)(v + ((long)b * T + row) * ldv + (long)hk * HD + ch * 8);
+        }
+    }
+    // Q fragments of this wave's query blocks: B operand, lane holds Q[query fr][32 ks + 8 fq .. +7]
+    bf16x8 qf[NQ][2];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        int qrow = (w + NW * i) * 16 + fr;
+        qrow = qrow < T ? qrow : T - 1;
+        const bf16* qp = q + ((long)b * T + qrow) * ldq + (long)hh * HD + 8 * fq;
+        qf[i][0] = *(const bf16x8*)qp;
+        qf[i][1] = *(const bf16x8*)(qp + 32);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT, row = c >> 3, ch = c & 7;
+        if (row < KROWS) *(u32x4*)(k_lds + row * KS + ch * 16) = kreg[i];
+        if (row < VROWS) *(u32x4*)(v_lds + row * VS + ch * 16) = vreg[i];
+    }
+    __syncthreads();
+
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        const int qb = w + NW * qi;
+        if (qb >= nkb) break;                                     // wave-uniform
+        const int q0 = qb * 16;
+        // ---- scores: S^T block kb = keys 16kb .. +15, this lane: keys 16kb + 4fq + {0..3} of query q0 + fr
+        f32x4 sc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            sc[kb] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kb < nkb) {
+                const char* kr = k_lds + (kb * 16 + fr) * KS + fq * 16;
+                const bf16x8 k0 = *(const bf16x8*)kr, k1 = *(const bf16x8*)(kr + 64);
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi][0], zero4, 0, 0, 0);
+                sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi][1], a, 0, 0, 0);
+            }
+        }
+        if (T & 15) {                                             // keys past T in the last block
+            const int kb = nkb - 1;
+#pragma unroll
+            for (int x = 0; x < NKB; ++x)
+                if (x == kb) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sc[x][i] = (x * 16 + 4 * fq + i < T) ? sc[x][i] : -INFINITY;
+                }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) m = fmaxf(m, fmaxf(fmaxf(sc[kb][0], sc[kb][1]), fmaxf(sc[kb][2], sc[kb][3])));
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float msc = m * scale_log2e;
+        // ---- P, row sum and O^T
+        f32x4 lacc = zero4, oacc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+        for (int st = 0; st < NPV; ++st) {
+            if (2 * st < nkb) {
+                bf16x8 pb;
+                const bool second = 2 * st + 1 < NKB;            // compile-time after unrolling: the last step of an odd NKB has one block
+                const f32x4 s1 = sc[second ? 2 * st + 1 : 2 * st];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pb[i] = (bf16)__builtin_amdgcn_exp2f(fmaf(sc[2 * st][i], scale_log2e, -msc));
+                    pb[4 + i] = second ? (bf16)__builtin_amdgcn_exp2f(fmaf(s1[i], scale_log2e, -msc)) : (bf16)0.f;
+                }
+                lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, lacc, 0, 0, 0);
+                const char* vr = v_lds + (32 * st + 4 * g + (i16 >> 2)) * VS + (4 * (i16 & 3)) * 2;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(vr + t * 32));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(vr + t * 32 + 16 * VS));
+                    typedef __attribute__((ext_vector_type(8))) short short8v;
+                    const short8v both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, both), pb, oacc[t], 0, 0, 0);
+                }
+            }
+        }
+        // every row of lacc is the row sum: lane (fr, *) holds l of query q0 + fr
+        const float l = lacc[0], inv = 1.0f / l;
+        if (lse && fq == 0 && q0 + fr < T) lse[((long)b * H + hh) * T + q0 + fr] = (msc + log2f(l)) * 0.69314718055994531f;
+        // ---- output: O^T[16t + 4fq + i][query fr] -> 16 x 32 bf16 scratch (two halves of the head dim) -> 16-byte row chunks
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const f32x4 a = oacc[2 * hf + tt];
+                float vals[4] = {a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv};
+                store_f<4>((bf16*)(o_lds + fr * OS) + 16 * tt + 4 * fq, vals);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS traffic is ordered; pins the compiler's order
+            const int row = lane >> 2, ch = lane & 3;
+            const u32x4 val = *(const u32x4*)(o_lds + row * OS + ch * 16);
+            if (q0 + row < T) *(u32x4*)(o + ((long)b * T + q0 + row) * ldo + (long)hh * HD + hf * 32 + ch * 8) = val;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+template <int NKB, int NW>
+int launch_fwd_short(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, long ldq, long ldk, long ldv,
+                     long ldo, float scale, hipStream_t st, int G) {
+    constexpr int LDS = NKB * 16 * 160 + ((NKB + 1) / 2) * 32 * 160 + NW * 16 * 80;
+    static bool attr[64] = {};
+    int dev = 0;
+    AV_HIP(hipGetDevice(&dev));
+    if (!attr[dev & 63]) {
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr[dev & 63] = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_short<NKB, NW>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse,
+                       T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
 template <int HD, int NW>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H, long ldq,
                long ldk, long ldv, long ldo, float scale, int causal, hipStream_t st, int G) {
@@ -274,6 +433,12 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
     if (impl == 1 || dtype == AV_F32 || (hd != 64 && hd != 128))
         return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st, G);
     if (hd == 64) {
+        // short non-causal self-attention (CLIP: 197 tokens, ViT-L/14: 257): whole-sequence scores in registers, exact two-pass softmax
+        static const bool short_off = getenv("AVLLM_ATTN_SHORT") && atoi(getenv("AVLLM_ATTN_SHORT")) == 0;
+        if (!causal && Tq == Tk && !short_off && B <= 65535) {
+            if (Tq <= 208) return launch_fwd_short<13, 7>(q, k, v, o, lse, B, Tq, H, ldq, ldk, ldv, ldo, scale, st, G);
+            if (Tq <= 272) return launch_fwd_short<17, 9>(q, k, v, o, lse, B, Tq, H, ldq, ldk, ldv, ldo, scale, st, G);
+        }
         // short sequences (CLIP: 197 tokens): one workgroup covers the whole sequence with 7 waves
         if (Tq <= 224 && Tq > 128 && Tk <= 224 && !causal) return launch_fwd<64, 7>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
         return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);

@@ -48,4 +48,7 @@ int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc,
 int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st);
 int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);
 int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st, const uint32_t* seed_dev = nullptr);
+bool av_lora_dx_masked_supported(int dtype, int N, int r, const long* ldt, const long* ldat, int nj, long ldr, long ldo);
+int av_lora_dx_masked(const void* const* T, const long* ldt, const void* const* AT, const long* ldat, const uint32_t* seeds, int nj, int r,
+                      const void* R, long ldr, void* out, long ldo, int M, int N, float p, const uint32_t* seed_dev, int dtype, hipStream_t st);
 int av_step_advance(avllm_step_state* state, const avllm_schedule* sched, hipStream_t st);

@@ -397,9 +397,16 @@ extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* 
         }
         AV_TRY(av_gemm(&g, st));
         if (lo.A_pad && drop) {       // d att += mask_o * (dto . A_o) / (1-p): the adapter's input gradient passes back through its dropout
+            const void* Tp[1] = {w.dto}; const void* Ap[1] = {lo.AT_pad};
+            const long lt[1] = {AVLLM_LORA_PAD}, la[1] = {lo.ld_at};
+            const uint32_t sd[1] = {m->dropout_seed + 4u * l + 3};
+            if (fuse_drop && av_lora_dx_masked_supported(dt, d, R, lt, la, 1, d, d)) {
+                AV_TRY(av_lora_dx_masked(Tp, lt, Ap, la, sd, 1, R, w.datt, d, w.datt, d, M, d, m->lora_dropout, m->dropout_seed_dev, dt, st));
+            } else {
             avllm_gemm_desc gm = gemm_desc(dt, w.dto, AVLLM_LORA_PAD, lo.AT_pad, lo.ld_at, w.datt, d, M, d, AVLLM_LORA_PAD);
             gm.R = w.datt; gm.ldr = d; gm.drop_seed = m->dropout_seed + 4u * l + 3; gm.drop_p = m->lora_dropout; gm.seed_dev = m->dropout_seed_dev;
             AV_TRY(av_gemm(&gm, st));
+            }
         }
         // ---- attention
         const char* qkv = (const char*)a.qkv;
@@ -435,6 +442,16 @@ extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* 
             if (any && !drop) { g.A2 = w.dtqkv; g.lda2 = 3 * AVLLM_LORA_PAD; g.B2 = P.lora[0].AT_pad; g.ldb2 = 3 * AVLLM_LORA_PAD; g.K2 = 3 * AVLLM_LORA_PAD; }
             AV_TRY(av_gemm(&g, st));
             if (any && drop) {
+                // all three adapters' input gradients in one pass over dX when the fused kernel applies (csrc/lora_dx.hip)
+                const void* Tp[3]; const void* Ap[3]; long lt[3], la[3]; uint32_t sd[3]; int nj = 0;
+                for (int j = 0; j < 3; ++j) {
+                    if (!P.lora[j].A_pad) continue;
+                    Tp[nj] = (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es; lt[nj] = 3 * AVLLM_LORA_PAD;
+                    Ap[nj] = P.lora[j].AT_pad; la[nj] = P.lora[j].ld_at; sd[nj] = m->dropout_seed + 4u * l + j; ++nj;
+                }
+                if (fuse_drop && av_lora_dx_masked_supported(dt, d, R, lt, la, nj, d, d)) {
+                    AV_TRY(av_lora_dx_masked(Tp, lt, Ap, la, sd, nj, R, w.dxn, d, w.dxn, d, M, d, m->lora_dropout, m->dropout_seed_dev, dt, st));
+                } else
                 for (int j = 0; j < 3; ++j) {
                     const avllm_lora_mod& lj = P.lora[j];
                     if (!lj.A_pad) continue;

@@ -710,6 +710,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
 // transposes its own 128x128 quadrant 16 rows at a time through a private 8-KiB slice of the remaining 32 KiB of LDS (same-wave LDS
 // traffic is in order: no workgroup barrier), and the accumulators are re-initialised for free by the first K-step's MFMAs taking 0 as
 // their C operand.  Buffers alternate by address arithmetic, so any K-step count and tile parity runs the same loop body.
+// B-operand (weight) fragment j of a wave reads LDS rows 32 (j >> 1) + 4 (j & 1) + 8 (fr >> 2) + (fr & 3) of its 128-row half: MFMA tiles 2p and
+// 2p+1 then hold, in lane (fr, fq), output columns 32p + 8fq + {0..3} and + {4..7} of row fr -- one 16-byte bf16 chunk per lane and tile
+// pair, stored straight from the accumulators (no LDS transpose in the epilogue).  Byte offset of fragment j from the lane's base row:
+#define WP_BOFF(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 128)
 template <int N, bool FIRST>
 __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2], const int (&lb)[2],
                                             const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
@@ -720,7 +724,7 @@ __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][
 #define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(base) : "memory")
     // la/lb[1]: this lane's k-half-1 fragment address in the CURRENT buffer; la/lb[0]: k-half 0 in the OTHER buffer (next K-step)
     if constexpr (h == 0) {
-        if constexpr (n < 16 && (n & 1)) AV_W_RD(FB[1][n >> 1], lb[1], (n >> 1) * 2048);
+        if constexpr (n < 16 && (n & 1)) AV_W_RD(FB[1][n >> 1], lb[1], WP_BOFF(n >> 1));
         if constexpr (n == 20) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (n == 21) __builtin_amdgcn_s_barrier();
         if constexpr (n >= 22 && n < 38 && !(n & 1)) AV_W_LD(vB[(n - 22) >> 1], pB, m0B + ((n - 22) >> 1) * 1024);
@@ -732,7 +736,7 @@ __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][
         if constexpr (n == 0) AV_W_LD(vA[4], pA, m0A + 4 * 1024);
         if constexpr (n == 26) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         if constexpr (n == 27) __builtin_amdgcn_s_barrier();
-        if constexpr (n >= 28 && n < 36) AV_W_RD(FB[0][n - 28], lb[0], (n - 28) * 2048);
+        if constexpr (n >= 28 && n < 36) AV_W_RD(FB[0][n - 28], lb[0], WP_BOFF(n - 28));
         if constexpr (n >= 37 && n < 53 && (n & 1)) AV_W_RD(FA[0][(n - 37) >> 1], la[0], ((n - 37) >> 1) * 2048);
         if constexpr (n == 32 || n == 40 || n == 48) AV_W_LD(vA[5 + (n - 32) / 8], pA, m0A + (5 + (n - 32) / 8) * 1024);
         if constexpr (n == 62) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -745,7 +749,7 @@ __device__ __forceinline__ void wpgemm_kstep(std::integer_sequence<int, Ns...>, 
     (wpgemm_step<Ns, FIRST>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
 }
 
-constexpr int WP_LDS = 2 * HSTAGE + 4 * 8192;                       // two stage buffers + one 16x128 fp32 transpose slice per wave = 160 KiB
+constexpr int WP_LDS = 2 * HSTAGE;                                  // two stage buffers; the epilogue does not touch LDS
 
 template <bool HAS2>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
@@ -757,11 +761,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     const int nt1 = g.K / BK, nt = nt1 + g.K2 / BK;                  // >= 2 (dispatcher)
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int pc0 = (fq ^ (fr & 7)) << 4, pc1 = ((4 + fq) ^ (fr & 7)) << 4;
-    const int rowA = lds0 + (wr * 128 + fr) * 128, rowB = lds0 + HBM_ * 128 + (wc * 128 + fr) * 128;
-    int la[2] = {rowA + HSTAGE + pc0, rowA + pc1}, lb[2] = {rowB + HSTAGE + pc0, rowB + pc1};     // current buffer = 0
+    // weight image: 16-byte chunk index ^ key(row), key(row) = (row & 3) | ((row >> 3) & 1) << 2, which keeps the remapped fragment reads
+    // (rows 8 (fr >> 2) + (fr & 3) + 4e + 32p) bank-conflict free; the activation image keeps chunk ^ (row & 7)
+    const int keyB = (fr & 3) | (((fr >> 2) & 1) << 2);
+    const int pcB0 = (fq ^ keyB) << 4, pcB1 = ((4 + fq) ^ keyB) << 4;
+    const int rowA = lds0 + (wr * 128 + fr) * 128, rowB = lds0 + HBM_ * 128 + (wc * 128 + 8 * (fr >> 2) + (fr & 3)) * 128;
+    int la[2] = {rowA + HSTAGE + pc0, rowA + pc1}, lb[2] = {rowB + HSTAGE + pcB0, rowB + pcB1};     // current buffer = 0
     int bo = 0;                                                      // byte offset of the current buffer
     const int mw = lds0 + wave * 8192;
     const unsigned ch = ((lane & 7) ^ (lane >> 3)) << 4, r0 = wave * 64 + (lane >> 3);
+    // source-side swizzle of the weight rows: LDS row wave*64 + 8q + (lane >> 3) has key ((lane >> 3) & 3) | (q & 1) << 2
+    const unsigned chB0 = ((lane & 7) ^ ((lane >> 3) & 3)) << 4, chB1 = ((lane & 7) ^ (((lane >> 3) & 3) | 4)) << 4;
 
     // Load context: the tile whose K-steps are being fetched (up to two K-steps ahead of the tile being multiplied).  Offsets as in the
     // one-shot kernel; the second K segment's (LoRA: one K-step per tile) are rebuilt in the K-steps that need them.
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const unsigned r = r0 + q * 8;
-            vA1[q] = __umul24(r < ma ? r : ma, la2) + ch; vB1[q] = __umul24(r < mb ? r : mb, lb2) + ch;
+            vA1[q] = __umul24(r < ma ? r : ma, la2) + ch; vB1[q] = __umul24(r < mb ? r : mb, lb2) + ((q & 1) ? chB1 : chB0);
         }
         tA1 = g.A + (long)lm0 * g.lda; tB1 = g.B + (long)ln0 * g.ldb;
     };
@@ -790,7 +800,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const unsigned r = r0 + q * 8;
-            va[q] = __umul24(r < ma ? r : ma, la2) + ch; vb[q] = __umul24(r < mb ? r : mb, lb2) + ch;
+            va[q] = __umul24(r < ma ? r : ma, la2) + ch; vb[q] = __umul24(r < mb ? r : mb, lb2) + ((q & 1) ? chB1 : chB0);
         }
         pa = g.A2 + (long)lm0 * g.lda2 + (long)(lt - nt1) * BK; pb = g.B2 + (long)ln0 * g.ldb2 + (long)(lt - nt1) * BK;
     };
@@ -814,9 +824,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
-        int a0 = rowA + pc0, b0 = rowB + pc0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { AV_W_RD(FB[0][j], b0, 0); b0 += 2048; }
+        int a0 = rowA + pc0;
+        const int b0 = rowB + pcB0;
+#define AV_WP_RDB(J) AV_W_RD(FB[0][J], b0, WP_BOFF(J))
+        AV_WP_RDB(0); AV_WP_RDB(1); AV_WP_RDB(2); AV_WP_RDB(3); AV_WP_RDB(4); AV_WP_RDB(5); AV_WP_RDB(6); AV_WP_RDB(7);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { AV_W_RD(FA[0][i], a0, 0); a0 += 2048; }
     }
@@ -838,9 +849,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         la[1] += d; lb[1] += d; la[0] -= d; lb[0] -= d; bo += d;
         advance();
     };
-    // epilogue geometry: item p of a 16-row block = row 4p + (lane >> 4), columns 8 (lane & 15) .. +7 of the wave's 128
-    float* cw = (float*)(smem + 2 * HSTAGE + wave * 8192);           // this wave's transpose slice: 16 rows x 128 fp32, 16-byte chunk ^ (row & 7)
-    const int c8 = lane & 15, prow = lane >> 4;
     for (int vid = blockIdx.x; vid < ntiles; vid += G) {
         kstep(std::true_type{});
 #pragma unroll 1
@@ -851,31 +859,33 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
 #define AV_W_PIN8(I) asm volatile("" : "+a"(acc[I][0]), "+a"(acc[I][1]), "+a"(acc[I][2]), "+a"(acc[I][3]), "+a"(acc[I][4]), "+a"(acc[I][5]), "+a"(acc[I][6]), "+a"(acc[I][7]))
         AV_W_PIN8(0); AV_W_PIN8(1); AV_W_PIN8(2); AV_W_PIN8(3); AV_W_PIN8(4); AV_W_PIN8(5); AV_W_PIN8(6); AV_W_PIN8(7);
 #undef AV_W_PIN8
+        // Epilogue straight from the accumulators: lane (fr, fq) holds, for row block i and column pair p, the 8 consecutive output columns
+        // 32p + 8fq .. +7 of row 16i + fr (acc[i][2p] = the first four, acc[i][2p+1] = the last four): bias / activation / residual on the
+        // fp32 values, one rounding, one 16-byte store per pair; a store instruction covers 16 rows x 64 contiguous bytes.
         int tm, tn;
         tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
-        const int m0 = tm * HBM_ + wr * 128, n = tn * HBN_ + wc * 128 + c8 * 8;
-        const bool ncol = n < g.e.N;
-        float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (g.e.bias && ncol) load_f<8>((const bf16*)g.e.bias + n, b);
-        // this lane's first row of the quadrant; item (i, p) is 16 i + 4 p rows further down: uniform (scalar) multiples of the row strides
-        bf16* const cp0 = (bf16*)g.e.C + (long)(m0 + prow) * g.e.ldc + n;
-        const bf16* const rp0 = g.e.R ? (const bf16*)g.e.R + (long)(m0 + prow) * g.e.ldr + n : nullptr;
+        const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
+        float b[4][8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[p][c] = 0.f;
+            if (g.e.bias && n + 32 * p < g.e.N) load_f<8>((const bf16*)g.e.bias + n + 32 * p, b[p]);
+        }
+        // this lane's first row; item (i, p) is 16 i rows down and 32 p columns right: uniform (scalar) multiples of the row strides
+        bf16* const cp0 = (bf16*)g.e.C + (long)m0 * g.e.ldc + n;
+        const bf16* const rp0 = g.e.R ? (const bf16*)g.e.R + (long)m0 * g.e.ldr + n : nullptr;
         const long ldc = g.e.ldc, ldr = g.e.R ? g.e.ldr : 0;
         auto run = [&](auto actc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(actc)::value;
 #pragma clang loop unroll(full)
             for (int i = 0; i < 8; ++i) {
+                const bool mrow = m0 + i * 16 < g.e.M;
 #pragma clang loop unroll(full)
-                for (int j = 0; j < 8; ++j) *(f32x4*)(cw + fr * 128 + (((j * 4 + fq) ^ (fr & 7)) << 2)) = acc[i][j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pins the compiler's ordering of the slice's writes and reads
-#pragma clang loop unroll(full)
-                for (int p = 0; p < 4; ++p) {
-                    const int row = p * 4 + prow, m = m0 + i * 16 + row;
-                    const f32x4 lo = *(const f32x4*)(cw + row * 128 + (((2 * c8) ^ (row & 7)) << 2));
-                    const f32x4 hi = *(const f32x4*)(cw + row * 128 + (((2 * c8 + 1) ^ (row & 7)) << 2));
-                    if (ncol && m < g.e.M) epilogue_fast8<ACT>(lo, hi, b, g.e.bias != nullptr, rp0 + (i * 16 + p * 4) * ldr, cp0 + (i * 16 + p * 4) * ldc);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int p = 0; p < 4; ++p)
+                    if (mrow && n + 32 * p < g.e.N)
+                        epilogue_fast8<ACT>(acc[i][2 * p], acc[i][2 * p + 1], b[p], g.e.bias != nullptr, rp0 ? rp0 + (i * 16) * ldr + 32 * p : nullptr,
+                                            cp0 + (i * 16) * ldc + 32 * p);
             }
         };
         if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
@@ -885,15 +895,16 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         // The next tile's k-half-0 fragments are read again here (its first K-step is complete in the current buffer: the last K-step's
         // barrier covered it) instead of being carried through the epilogue: 64 registers the epilogue code can use
         if (vid + G < ntiles) {
-            int a0 = la[1] - pc1 + pc0, b0 = lb[1] - pc1 + pc0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { AV_W_RD(FB[0][j], b0, 0); b0 += 2048; }
+            int a0 = la[1] - pc1 + pc0;
+            const int b0 = lb[1] - pcB1 + pcB0;
+            AV_WP_RDB(0); AV_WP_RDB(1); AV_WP_RDB(2); AV_WP_RDB(3); AV_WP_RDB(4); AV_WP_RDB(5); AV_WP_RDB(6); AV_WP_RDB(7);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { AV_W_RD(FA[0][i], a0, 0); a0 += 2048; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // in-flight DMA writes must not outlive the workgroup's LDS allocation
+#undef AV_WP_RDB
 #undef AV_W_RD
 #undef AV_W_LD
 }

@@ -69,6 +69,15 @@ int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t 
 int avllm_gemm_tn_drop(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
                        float* out, int64_t ldo, float alpha, uint32_t drop_seed, float drop_p, int32_t dtype, void* stream);
 
+/* Input gradient of up to three LoRA adapters that share one input x, under lora_dropout, in one pass (bf16):
+ *   out[M,N] = R[M,N] + sum_j keep(seeds[j] (+ *seed_dev), m*N+n, p)/(1-p) * (T_j[M,r] . A_j[r,N])
+ * autograd of peft's lora_B(lora_A(dropout(x))) w.r.t. x (clip_whisper_model.py:961-1005).  T_j [M, >= 32 cols] (zeros past the rank, row
+ * stride ldt[j]); AT_j = the padded transposed image of A_j [N, >= 32 cols] (avllm_lora_pack's AT_pad, row stride ldat[j]); T / AT / ldt /
+ * ldat / seeds are HOST arrays of nj <= 3 entries; out may alias R.  N % 128 == 0, r <= 32. */
+int avllm_lora_dx_masked(const void* const* T, const int64_t* ldt, const void* const* AT, const int64_t* ldat, const uint32_t* seeds,
+                         int32_t nj, int32_t r, const void* R, int64_t ldr, void* out, int64_t ldo, int32_t M, int32_t N, float p,
+                         const uint32_t* seed_dev, int32_t dtype, void* stream);
+
 /* Per-step scalars kept in DEVICE memory so that a training step is the same launch sequence every time and can be captured in a
  * hipGraph (trainer/clip_whisper_trainer.py:433-490 recomputes them on the host each step: scheduler.step() :464, the optimizer's
  * step count, torch's dropout RNG).  avllm_step_advance is a one-thread kernel: step += 1, then

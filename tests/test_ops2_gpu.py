@@ -325,3 +325,27 @@ def test_gemm_16wave_narrow_and_wide_epilogues(dev):
         assert out.view(100, 10, N)[:, 0].abs().max().item() == 0
     finally:
         lib.avllm_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("T", [1, 10, 16, 17, 50, 197, 208, 209, 257, 272])
+def test_attention_short_noncausal_every_length(dev, T):
+    """The whole-sequence-in-registers kernel (hd 64, non-causal, T <= 272: CLIP ViT-B/16 = 197, ViT-L/14 = 257): every block-edge
+    length, output and log-sum-exp against fp32 torch; plus one dominant key per query (softmax far from uniform) and grouped heads."""
+    from test_ops_gpu import _attn_ref
+    B, H, hd = 3, 2, 64
+    qkv = rnd(B * T, 3 * H * hd, dtype=torch.bfloat16, seed=31)
+    if T > 4:
+        qkv[T // 2, H * hd:H * hd + hd] = qkv[T - 1, 0:hd] * 6          # a key aligned with the last query of item 0, head 0
+    o, lse = ops.attention_fwd(qkv, B, T, H, hd, False)
+    ro, rl = _attn_ref(qkv, B, T, H, hd, False)
+    close(o, ro, 3e-2, 2e-2, f"short attention T={T}")
+    close(lse, rl, 2e-2, 1e-4, "lse")
+    if T in (50, 197):                                                    # 4 query heads on 2 key/value heads
+        Hq, Hkv = 4, 2
+        x = rnd(B * T, (Hq + 2 * Hkv) * hd, dtype=torch.bfloat16, seed=32)
+        og, _ = ops.attention_fwd(x, B, T, Hq, hd, False, kv_heads=Hkv)
+        q, k, v = x.float().split([Hq * hd, Hkv * hd, Hkv * hd], dim=1)
+        k = k.view(B * T, Hkv, 1, hd).expand(-1, -1, Hq // Hkv, -1).reshape(B * T, Hq * hd)
+        v = v.view(B * T, Hkv, 1, hd).expand(-1, -1, Hq // Hkv, -1).reshape(B * T, Hq * hd)
+        rg, _ = _attn_ref(torch.cat([q, k, v], 1), B, T, Hq, hd, False)
+        close(og, rg, 3e-2, 2e-2, f"short attention grouped T={T}")

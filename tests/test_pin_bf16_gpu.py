@@ -60,6 +60,45 @@ def test_masked_dx_gemm_epilogue_bf16(dev, M, N, K, with_r):
     assert ((other - exp16).abs() > tol).float().mean().item() > p
 
 
+@pytest.mark.parametrize("M,N,nj,ld", [(4096, 4096, 3, 192), (4096, 4096, 1, 64), (1000, 256, 2, 192), (40, 128, 3, 64)])
+def test_fused_adapter_input_gradient_under_dropout(dev, M, N, nj, ld):
+    """avllm_lora_dx_masked: out = R + sum_j mask_j o (T_j . A_j)/(1-p) in one pass over dX (q/k/v: three adapters, one launch) against
+    fp32 torch with the avllm_dropout masks, within one bf16 ulp; in place (out aliases R) as the backward pass uses it; and equal to
+    the per-adapter masked GEMMs it replaces up to their three intermediate roundings."""
+    from avllm import ops
+    p, r = 0.05, 16
+    seeds = [1000 + 4 * 7 + j for j in range(nj)]
+    Tbig = torch.zeros(M, ld, device=dev, dtype=torch.bfloat16)
+    ATbig = torch.zeros(N, ld, device=dev, dtype=torch.bfloat16)
+    Ts, ATs = [], []
+    for j in range(nj):
+        c0 = j * 64 if ld == 192 else 0
+        if ld == 64 and j > 0:                                        # separate images per adapter
+            Tbig2, ATbig2 = torch.zeros_like(Tbig), torch.zeros_like(ATbig)
+        else:
+            Tbig2, ATbig2 = Tbig, ATbig
+        Tbig2[:, c0:c0 + r] = rnd(M, r, dtype=torch.bfloat16, seed=60 + j)
+        ATbig2[:, c0:c0 + r] = rnd(N, r, dtype=torch.bfloat16, seed=70 + j, scale=0.1)
+        Ts.append(Tbig2[:, c0:c0 + 64]); ATs.append(ATbig2[:, c0:c0 + 64])
+    R = rnd(M, N, dtype=torch.bfloat16, seed=80)
+    exp = R.float()
+    for j in range(nj):
+        mask = ops.dropout(torch.ones(M, N, device=dev, dtype=torch.float32), seeds[j], p)
+        exp = exp + mask * (Ts[j][:, :r].float() @ ATs[j][:, :r].float().t())
+    exp16 = exp.to(torch.bfloat16).float()
+    got = ops.lora_dx_masked(Ts, ATs, seeds, r, p, R=R).float()
+    err = (got - exp16).abs()
+    tol = exp16.abs() * 2.0 ** -7 + 1e-6
+    assert int((err > tol).sum()) == 0, (err.max().item(), int((err > tol).sum()))
+    inplace = R.clone()
+    ops.lora_dx_masked(Ts, ATs, seeds, r, p, R=inplace, out=inplace)
+    assert torch.equal(inplace.float(), got)
+    seq = R.clone()                                                  # what round 1 did: one masked K=64 GEMM per adapter, each rounding dX
+    for j in range(nj):
+        seq = ops.gemm(Ts[j], ATs[j], R=seq, drop=(seeds[j], p))
+    assert rel_l2(seq.float(), got) < 4e-3
+
+
 @pytest.mark.parametrize("M", [8, 16, 200, 4096])
 def test_rank_side_gemm_fused_a_dropout_every_m(dev, M):
     """t = alpha * dropout(x) . A_pad^T with the mask generated on the A fragments (a_drop) == the same GEMM on a materialised
