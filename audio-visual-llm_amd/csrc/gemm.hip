@@ -144,6 +144,7 @@ struct GemmArgs {
     long lda, ldb, lda2, ldb2;
     int K, K2;
     int wide_epi;        // outputs/bias/residual 16-byte aligned, N % 8 == 0: LDS-staged epilogue with 16-byte row-coalesced stores
+    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bits 4.. = start-stagger phases
     EpiParams e;
 };
 
@@ -805,6 +806,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         pa = g.A2 + (long)lm0 * g.lda2 + (long)(lt - nt1) * BK; pb = g.B2 + (long)ln0 * g.ldb2 + (long)(lt - nt1) * BK;
     };
     set_ctx(lvid);
+    {   // experiment: de-phase the workgroups (all tiles take the same time, so the whole grid otherwise reaches its epilogue store burst at once)
+        const int phases = g.dbg >> 4;
+        if (phases > 1) {
+            const int ph = (blockIdx.x >> 3) % phases;
+            const int n = ph * (nt * 2100 + 11000) / (phases * 6400);
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(100);
+        }
+    }
 #pragma unroll 1
     for (int s = 0; s < 2; ++s) {
         unsigned va[8], vb[8];
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
                 const bool mrow = m0 + i * 16 < g.e.M;
 #pragma clang loop unroll(full)
                 for (int p = 0; p < 4; ++p)
-                    if (mrow && n + 32 * p < g.e.N)
+                    if (mrow && n + 32 * p < g.e.N && !(g.dbg & 1))
                         epilogue_fast8<ACT>(acc[i][2 * p], acc[i][2 * p + 1], b[p], g.e.bias != nullptr, rp0 ? rp0 + (i * 16) * ldr + 32 * p : nullptr,
                                             cp0 + (i * 16) * ldc + 32 * p);
             }
@@ -1232,7 +1241,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
-        g.wide_epi = wide_ok;
+        g.wide_epi = wide_ok; g.dbg = 0;
         hipLaunchKernelGGL(gemm_smallm_kernel, dim3(d->N / 16), dim3(SK_WAVES * 64), 0, st, g);
     } else if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
                d->K % (32 * SK_WAVES) == 0 && (d->M >= 256 || d->a_drop_p > 0.f)) {
@@ -1258,6 +1267,8 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
         g.wide_epi = wide_ok;
+        static const int dbg_env = getenv("AVLLM_GEMM_DBG") ? atoi(getenv("AVLLM_GEMM_DBG")) : 0;
+        g.dbg = dbg_env;
         GemmDevState* ds = gemm_dev_state();
         if (!ds->attr_base) {
             AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
