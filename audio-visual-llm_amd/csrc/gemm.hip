@@ -715,10 +715,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w_kernel(GemmArgs g) {
 // 2p+1 then hold, in lane (fr, fq), output columns 32p + 8fq + {0..3} and + {4..7} of row fr -- one 16-byte bf16 chunk per lane and tile
 // pair, stored straight from the accumulators (no LDS transpose in the epilogue).  Byte offset of fragment j from the lane's base row:
 #define WP_BOFF(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 128)
-template <int N, bool FIRST>
+// MODE 0: any K-step but a tile's first; 1: a tile's first K-step (accumulators start from 0); 2: the same right after the epilogue of a
+// tile that lay fully inside the matrix.  vmcnt counts loads and stores together in issue order, so the counted wait of the K-step would
+// also wait for the 32 epilogue stores issued just before it (their write acknowledgements take several microseconds when the whole
+// grid stores at once); mode 2 allows exactly those 32 to stay in flight: everything OLDER (the K-step's operands) has still landed.
+template <int N, int MODE>
 __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2], const int (&lb)[2],
                                             const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
     constexpr int h = N >> 6, n = N & 63, I = n >> 3, J = n & 7;
+    constexpr bool FIRST = MODE != 0;
     if constexpr (FIRST && h == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
 #define AV_W_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -735,7 +740,7 @@ __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][
         if constexpr (n == 52 || n == 55 || n == 58 || n == 61) AV_W_LD(vA[(n - 52) / 3], pA, m0A + ((n - 52) / 3) * 1024);
     } else {
         if constexpr (n == 0) AV_W_LD(vA[4], pA, m0A + 4 * 1024);
-        if constexpr (n == 26) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        if constexpr (n == 26) { if constexpr (MODE == 2) asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
         if constexpr (n == 27) __builtin_amdgcn_s_barrier();
         if constexpr (n >= 28 && n < 36) AV_W_RD(FB[0][n - 28], lb[0], WP_BOFF(n - 28));
         if constexpr (n >= 37 && n < 53 && (n & 1)) AV_W_RD(FA[0][(n - 37) >> 1], la[0], ((n - 37) >> 1) * 2048);
@@ -744,10 +749,10 @@ __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][
     }
 }
 
-template <bool FIRST, int... Ns>
+template <int MODE, int... Ns>
 __device__ __forceinline__ void wpgemm_kstep(std::integer_sequence<int, Ns...>, f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8], bf16x8 (&FB)[2][8], const int (&la)[2],
                                              const int (&lb)[2], const unsigned (&vA)[8], const unsigned (&vB)[8], const bf16* pA, const bf16* pB, int m0A, int m0B) {
-    (wpgemm_step<Ns, FIRST>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
+    (wpgemm_step<Ns, MODE>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
 }
 
 constexpr int WP_LDS = 2 * HSTAGE;                                  // two stage buffers; the epilogue does not touch LDS
@@ -807,7 +812,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     };
     set_ctx(lvid);
     {   // experiment: de-phase the workgroups (all tiles take the same time, so the whole grid otherwise reaches its epilogue store burst at once)
-        const int phases = g.dbg >> 4;
+        // measured (tools/gemm_epi_experiment.sh, clip qkv 394000x2304x768): 1448 us in lockstep, 1292 us with two phases (4 or 8: the same);
+        // a one-round launch only pays the delay, hence >= 6 rounds.  dbg bits 4.. override the phase count (1 = off)
+        const int phases = (g.dbg >> 4) ? (g.dbg >> 4) : (ntiles >= 6 * G ? 2 : 1);
         if (phases > 1) {
             const int ph = (blockIdx.x >> 3) % phases;
             const int n = ph * (nt * 2100 + 11000) / (phases * 6400);
@@ -842,8 +849,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     using Seq = std::make_integer_sequence<int, 128>;
-    auto kstep = [&](auto firstc) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(firstc)::value;
+    auto kstep = [&](auto modec) __attribute__((always_inline)) {
+        constexpr int FIRST = decltype(modec)::value;                // MODE of wpgemm_step
         if constexpr (HAS2) {
             unsigned va[8], vb[8];
             const bf16 *pa = tA1 + (long)lt * BK, *pb = tB1 + (long)lt * BK;
@@ -858,10 +865,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         la[1] += d; lb[1] += d; la[0] -= d; lb[0] -= d; bo += d;
         advance();
     };
+    bool stores_in_flight = false;                                   // the previous tile's epilogue issued all of its 32 stores
     for (int vid = blockIdx.x; vid < ntiles; vid += G) {
-        kstep(std::true_type{});
+        if (stores_in_flight) kstep(std::integral_constant<int, 2>{});
+        else kstep(std::integral_constant<int, 1>{});
 #pragma unroll 1
-        for (int t = 1; t < nt; ++t) kstep(std::false_type{});
+        for (int t = 1; t < nt; ++t) kstep(std::integral_constant<int, 0>{});
         // result latency of the last MFMAs (invisible to the compiler's hazard recogniser): nops, and every accumulator named as an in/out
         // operand so that compiler-generated readers stay behind them
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -874,6 +883,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         int tm, tn;
         tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
         const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
+        stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 1);      // wave-uniform: every lane stores all 32 chunks
         float b[4][8];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
