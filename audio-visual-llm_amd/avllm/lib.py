@@ -60,6 +60,11 @@ class Llama(C.Structure):
                [(n, vp) for n in ("dropout_seed_dev", "embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))]
 
 
+class GemmF8Desc(C.Structure):
+    _fields_ = [("A", vp), ("SA", vp), ("B", vp), ("SB", vp), ("C", vp), ("bias", vp), ("R", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("ldr", i64), ("M", i32), ("N", i32), ("K", i32), ("act", i32)]
+
+
 class StepState(C.Structure):
     """avllm_step_state: per-step scalars in DEVICE memory (this mirror is only used for sizes / field offsets / host reads)."""
     _fields_ = [("step", C.c_uint32), ("dropout_seed", C.c_uint32), ("lr", f32), ("bc1", f32), ("bc2_sqrt", f32), ("skipped", f32),
@@ -109,6 +114,9 @@ _SIGS = {
     "avllm_grad_sumsq": ([vp, i64, vp, vp], i32),
     "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp, vp], i32),
     "avllm_step_advance": ([vp, C.POINTER(Schedule), vp], i32),
+    "avllm_mx_scale_bytes": ([i32, i32], sz),
+    "avllm_mx_quantize": ([vp, i64, i32, i32, vp, i64, vp, i32, i32, vp], i32),
+    "avllm_gemm_f8": ([C.POINTER(GemmF8Desc), vp], i32),
     "avllm_lora_dx_masked": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(C.c_uint32), i32, i32, vp, i64, vp, i64, i32,
                               i32, f32, vp, i32, vp], i32),
     "avllm_llama_lora_bwd_layers": ([C.POINTER(Llama), vp, i32, i32, vp, f32, vp, sz, i32, i32, LAYER_CB, vp, vp], i32),

@@ -211,6 +211,33 @@ def lora_dx_masked(Ts, ATs, seeds, r, p, R=None, out=None, seed_dev=None):
     return out
 
 
+def mx_quantize(x, layout=0):
+    """x [R,K] bf16/f32 -> (q uint8 [R,K] e4m3, scale image uint8 tensor): OCP-MX block scaling, 32 elements per E8M0 scale.
+    layout 0 = activation side, 1 = weight side of avllm_gemm_f8."""
+    lib = L.load()
+    R, K = x.shape
+    q = torch.empty(R, K, device=x.device, dtype=torch.uint8)
+    s = torch.zeros(lib.avllm_mx_scale_bytes(R, K), device=x.device, dtype=torch.uint8)
+    L.check(lib.avllm_mx_quantize(L.ptr(x), _ld(x), R, K, L.ptr(q), K, L.ptr(s), layout, L.dt_of(x), L.stream_ptr()))
+    return q, s
+
+
+def gemm_f8(Aq, As, Bq, Bs, out=None, bias=None, R=None, act=L.ACT_NONE):
+    """out[M,N] (bf16) = act(A.B^T + bias) + R on the block-scaled fp8 matrix pipe; (Aq, As) / (Bq, Bs) from mx_quantize(layout 0 / 1)."""
+    M, K = Aq.shape
+    N = Bq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=Aq.device, dtype=torch.bfloat16)
+    d = L.GemmF8Desc()
+    d.A, d.SA, d.B, d.SB, d.C, d.bias = L.ptr(Aq), L.ptr(As), L.ptr(Bq), L.ptr(Bs), L.ptr(out), L.ptr(bias)
+    d.lda, d.ldb, d.ldc = _ld(Aq), _ld(Bq), _ld(out)
+    if R is not None:
+        d.R, d.ldr = L.ptr(R), _ld(R)
+    d.M, d.N, d.K, d.act = M, N, K, act
+    L.check(L.load().avllm_gemm_f8(C.byref(d), L.stream_ptr()))
+    return out
+
+
 def step_advance(state, base_lr, total_steps, warmup_steps=0, beta1=0.9, beta2=0.95, rank=0):
     """One-thread kernel: state.step += 1 and this step's lr / bias corrections / dropout seed (include/avllm.h avllm_step_state)."""
     sc = L.Schedule(base_lr, beta1, beta2, int(warmup_steps), int(total_steps), int(rank))

@@ -51,4 +51,6 @@ int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p,
 bool av_lora_dx_masked_supported(int dtype, int N, int r, const long* ldt, const long* ldat, int nj, long ldr, long ldo);
 int av_lora_dx_masked(const void* const* T, const long* ldt, const void* const* AT, const long* ldat, const uint32_t* seeds, int nj, int r,
                       const void* R, long ldr, void* out, long ldo, int M, int N, float p, const uint32_t* seed_dev, int dtype, hipStream_t st);
+int av_mx_quantize(const void* x, long ldx, int R, int K, void* q, long ldq, void* scales, int layout, int dtype, hipStream_t st);
+int av_gemm_f8(const avllm_gemm_f8_desc* d, hipStream_t st);
 int av_step_advance(avllm_step_state* state, const avllm_schedule* sched, hipStream_t st);

@@ -17,6 +17,7 @@
 // f32 kernel (strict-parity mode): 64x64x16 tile on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "common.h"
 #include "avllm_internal.h"
+#include "gemm_shared.h"
 #include <stdlib.h>
 #include <utility>
 #include <type_traits>
@@ -100,40 +101,7 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n
     else store_f<8>((bf16*)e.C + orow * e.ldc + n0, v);
 }
 
-// Lean item of the LDS-staged epilogue for the common case (bf16 output, alpha = 1, no dropout, no row remap, plain residual, tile fully
-// inside the matrix): the general epilogue_store8 spends most of its instructions on 64-bit index arithmetic and on uniform branches
-// around features these calls do not use.  lo/hi = the two fp32 LDS chunks of this item, b = the thread's bias (zeros without one).
-template <int ACT>
-__device__ __forceinline__ void epilogue_fast8(const f32x4 lo, const f32x4 hi, const float (&b)[8], bool has_b, const bf16* rp, bf16* cp) {      // rp may alias cp (in-place residual)
-    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    if (has_b) {                                                   // uniform
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += b[i];
-    }
-    if constexpr (ACT != AV_ACT_NONE) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], ACT);
-    }
-    if (rp) {
-        const bf16x8 r = *(const bf16x8*)rp;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
-    }
-    store_f<8>(cp, v);
-}
-
-// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
-// range of logical tile ids.  Bijective for any grid size (cdna guide §5, "XCD swizzle must be bijective").
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (bid >> 3);
-}
-
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-    if (tiles_m <= 32) { tm = id % tiles_m; tn = id / tiles_m; }      // weights streamed once, all row tiles adjacent
-    else               { tn = id % tiles_n; tm = id / tiles_n; }      // activations streamed once
-}
+using avg::epilogue_fast8; using avg::xcd_remap; using avg::tile_coords;
 
 // ------------------------------------------------------------------------------------------ bf16
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -144,7 +112,7 @@ struct GemmArgs {
     long lda, ldb, lda2, ldb2;
     int K, K2;
     int wide_epi;        // outputs/bias/residual 16-byte aligned, N % 8 == 0: LDS-staged epilogue with 16-byte row-coalesced stores
-    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bits 4.. = start-stagger phases
+    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bit 1 = strict first-K-step wait, bits 4.. = start-stagger phases (1 = off)
     EpiParams e;
 };
 
@@ -883,7 +851,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         int tm, tn;
         tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
         const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
-        stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 1);      // wave-uniform: every lane stores all 32 chunks
+        stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 3);      // dbg bit 1: experiment, strict wait      // wave-uniform: every lane stores all 32 chunks
         float b[4][8];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {

@@ -1,0 +1,42 @@
+// Pieces shared by the bf16 (gemm.hip) and the block-scaled fp8 (fp8.hip) persistent 256x256 GEMM kernels.
+#pragma once
+#include "common.h"
+
+namespace avg {
+
+// Lean item of the LDS-staged epilogue for the common case (bf16 output, alpha = 1, no dropout, no row remap, plain residual, tile fully
+// inside the matrix): the general epilogue_store8 spends most of its instructions on 64-bit index arithmetic and on uniform branches
+// around features these calls do not use.  lo/hi = the two fp32 LDS chunks of this item, b = the thread's bias (zeros without one).
+template <int ACT>
+__device__ __forceinline__ void epilogue_fast8(const f32x4 lo, const f32x4 hi, const float (&b)[8], bool has_b, const bf16* rp, bf16* cp) {      // rp may alias cp (in-place residual)
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (has_b) {                                                   // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += b[i];
+    }
+    if constexpr (ACT != AV_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_apply_fast(v[i], ACT);
+    }
+    if (rp) {
+        const bf16x8 r = *(const bf16x8*)rp;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+    }
+    store_f<8>(cp, v);
+}
+
+// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
+// range of logical tile ids.  Bijective for any grid size (cdna guide §5, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if (tiles_m <= 32) { tm = id % tiles_m; tn = id / tiles_m; }      // weights streamed once, all row tiles adjacent
+    else               { tn = id % tiles_n; tm = id / tiles_n; }      // activations streamed once
+}
+
+}  // namespace avg

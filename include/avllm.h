@@ -78,6 +78,26 @@ int avllm_lora_dx_masked(const void* const* T, const int64_t* ldt, const void* c
                          int32_t nj, int32_t r, const void* R, int64_t ldr, void* out, int64_t ldo, int32_t M, int32_t N, float p,
                          const uint32_t* seed_dev, int32_t dtype, void* stream);
 
+/* ---- block-scaled fp8 (OCP MX: e4m3 elements + one E8M0 scale per 32 K elements; BASELINE config 5, "fp8 MFMA").  The reference has no
+ * such mode (clip_whisper_model.py:164: only use_fp16); these entry points give nn.Linear's y = act(x W^T + b) + R on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with fp32 accumulation, bf16 output.
+ * avllm_mx_quantize: x [R,K] (bf16 or f32, row stride ldx) -> q uint8 [R,K] (row stride ldq bytes) + the scale image of
+ * avllm_mx_scale_bytes(R,K) bytes.  layout 0 = activation side, 1 = weight side (csrc/fp8.hip, "Formats"). */
+size_t avllm_mx_scale_bytes(int32_t R, int32_t K);
+int avllm_mx_quantize(const void* x, int64_t ldx, int32_t R, int32_t K, void* q, int64_t ldq, void* scales, int32_t layout, int32_t dtype,
+                      void* stream);
+typedef struct avllm_gemm_f8_desc {
+    const void* A;  const void* SA;     /* activations: q [M,K] (layout 0 scales) */
+    const void* B;  const void* SB;     /* weights:     q [N,K] (layout 1 scales), nn.Linear orientation */
+    void* C;                            /* bf16 [M,N] */
+    const void* bias;                   /* bf16 [N] or NULL */
+    const void* R;                      /* bf16 residual [M,N] or NULL (may alias C) */
+    int64_t lda, ldb, ldc, ldr;
+    int32_t M, N, K;                    /* K % 128 == 0 */
+    int32_t act;
+} avllm_gemm_f8_desc;
+int avllm_gemm_f8(const avllm_gemm_f8_desc* d, void* stream);
+
 /* Per-step scalars kept in DEVICE memory so that a training step is the same launch sequence every time and can be captured in a
  * hipGraph (trainer/clip_whisper_trainer.py:433-490 recomputes them on the host each step: scheduler.step() :464, the optimizer's
  * step count, torch's dropout RNG).  avllm_step_advance is a one-thread kernel: step += 1, then

@@ -127,3 +127,34 @@ def test_grouped_query_golden(golden_dir):
     cfg.max_seq_len = 256
     ids = O.generate(W, cfg, audio, video, None, max_new_tokens=10, eos_token_id=2)
     assert torch.equal(ids, torch.from_numpy(g["generate_ids"]))
+
+
+def test_mxfp8_restatement_matches_the_mx_rule():
+    """oracle/mxfp8.py against the OCP MX definition spelled out independently (numpy, element by element on small blocks): shared
+    exponent floor(log2(amax)) - 8, e4m3fn grid with round-to-nearest-even, saturation at 448, zero blocks."""
+    import numpy as np
+    from oracle import mxfp8 as MX
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((6, 64)).astype(np.float32)
+    x[0, :32] = 0
+    x[1, 5] = 1000.0
+    x[2, 32:] *= 1e-5
+    x[3, 7] = 510.0 * 2.0 ** 5        # scaled value 510 > 448 -> saturates
+    codes, e = MX.quantize(torch.from_numpy(x))
+    deq = MX.dequantize(codes, e).numpy()
+    grid = sorted({(1 + m / 8) * 2.0 ** ex for ex in range(-6, 9) for m in range(8)} | {m / 8 * 2.0 ** -6 for m in range(8)})
+    grid = np.array([g for g in grid if g <= 448.0])
+    for r in range(6):
+        for b in range(2):
+            blk = x[r, 32 * b:32 * b + 32]
+            amax = np.abs(blk).max()
+            ee = -127 if amax == 0 else int(np.floor(np.log2(amax))) - 8
+            assert int(e[r, b]) == max(-127, ee)
+            for v, d in zip(blk, deq[r, 32 * b:32 * b + 32]):
+                t = min(abs(v) / 2.0 ** ee, 448.0) if amax > 0 else 0.0
+                j = np.searchsorted(grid, t)
+                cands = [grid[max(j - 1, 0)], grid[min(j, len(grid) - 1)]]
+                best = min(cands, key=lambda g: abs(g - t))
+                if abs(cands[0] - t) == abs(cands[1] - t):                      # tie: even mantissa
+                    best = cands[0] if (np.frexp(cands[0])[0] * 16) % 2 == 0 else cands[1]
+                assert abs(abs(d) - best * 2.0 ** ee) <= 1e-12 * max(1.0, abs(d)), (r, b, v, d, best * 2.0 ** ee)
