@@ -15,6 +15,11 @@
 //          layout 1 (weights, MFMA "A" side):      row = 128 (rb >> 1) + 32 (j >> 1) + 4 (j & 1) + 8 (fr >> 2) + (fr & 3),  j = 4 (rb & 1) + i
 //              -- the column-interleaved fragment order of the 256x256 kernels (gemm.hip WP_BOFF): tiles 2p / 2p+1 give a lane 8
 //              consecutive output columns, stored straight from the accumulators.
+// Operand layout of v_mfma_scale_f32_16x16x128_f8f6f4 (measured: tools/ubench/mfma_scale_probe.hip): lane (r, G) (r = lane & 15 the
+// row / column, G = lane >> 4) holds in VGPRs 0-3 the K elements [16 G, 16 G + 16) and in VGPRs 4-7 the elements [64 + 16 G, 64 + 16 G + 16)
+// of the 128-element K-step -- the 16-byte chunks G and 4 + G of a 128-byte row -- and its scale register carries the E8M0 byte of MX
+// block G = elements [32 G, 32 G + 32) of that row.  (A lane's scale therefore does NOT cover the lane's own 32 bytes: block 0 is the
+// low halves of lane groups 0 and 1, block 2 their high halves.)
 // E8M0 exponent rule (OCP MX v1.0 §6.3): e = floor(log2(amax)) - 8 (emax of e4m3), elements = RNE(x * 2^-e) saturated to +-448.
 #include "common.h"
 #include "avllm_internal.h"
@@ -114,13 +119,13 @@ __global__ __launch_bounds__(256) void gemm_f8_ref_kernel(GemmF8Args g) {
     for (int i = 0; i < 4; ++i) {
         int m = m0 + 16 * i + fr;
         m = m < g.e.M ? m : g.e.M - 1;
-        ap[i] = g.A + (long)m * g.lda + fq * 32;
+        ap[i] = g.A + (long)m * g.lda + fq * 16;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         int n = n0 + 32 * (j >> 1) + 4 * (j & 1) + 8 * (fr >> 2) + (fr & 3);
         n = n < g.e.N ? n : g.e.N - 1;
-        bp[j] = g.B + (long)n * g.ldb + fq * 32;
+        bp[j] = g.B + (long)n * g.ldb + fq * 16;
     }
     for (int t = 0; t < g.K / 128; ++t) {
         const int sa = (int)g.SA[(((long)t * g.RBA + rbA) * 4 + fq) * 16 + fr];
@@ -128,12 +133,12 @@ __global__ __launch_bounds__(256) void gemm_f8_ref_kernel(GemmF8Args g) {
         v8i fa[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const v4i lo = *(const v4i*)(ap[i] + t * 128), hi = *(const v4i*)(ap[i] + t * 128 + 16);
+            const v4i lo = *(const v4i*)(ap[i] + t * 128), hi = *(const v4i*)(ap[i] + t * 128 + 64);
             fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const v4i lo = *(const v4i*)(bp[j] + t * 128), hi = *(const v4i*)(bp[j] + t * 128 + 16);
+            const v4i lo = *(const v4i*)(bp[j] + t * 128), hi = *(const v4i*)(bp[j] + t * 128 + 64);
             const v8i fb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const int sb = j < 4 ? sb0 : sb1;
 #define AV_F8_MFMA(I, OB)                                                                                                               \

@@ -6,8 +6,8 @@
 // at twice the K); the pipeline never drains between tiles; the epilogue stores 16-byte bf16 chunks straight from the accumulators
 // (column-interleaved weight fragments, gemm.hip WP_BOFF).
 //
-// What differs: one v_mfma_scale_f32_16x16x128_f8f6f4 consumes a whole 128-element row slice of each operand (8 VGPRs = the lane's 32
-// consecutive K bytes, read as two ds_read_b128), so a K-step is 64 MFMAs of 32 cycles instead of 128 of 16, and a fragment cannot be
+// What differs: one v_mfma_scale_f32_16x16x128_f8f6f4 consumes a whole 128-element row slice of each operand (8 VGPRs = the 16-byte chunks
+// fq and 4 + fq of the lane's row, two ds_read_b128 -- the same two chunks the bf16 kernel reads as its k-halves), so a K-step is 64 MFMAs of 32 cycles instead of 128 of 16, and a fragment cannot be
 // double-buffered by k-halves.  Fragments are instead reloaded IN PLACE as they die: MFMA order = weight columns 0..5 column-major, then
 // row-major over columns 6,7; weight fragment J (< 6) is reloaded from the OTHER stage buffer (next K-step) right after its column,
 // activation fragment I right after its two last products; the six reads that cannot be placed (FA[7], FB[6], FB[7]) trail into the next
@@ -16,8 +16,7 @@
 // "everyone has finished reading the current buffer", after which the DMA for K-step t+2 overwrites the current buffer.
 // Block scales: one dword per lane, K-step and 64-row group holds the E8M0 bytes of four MFMA tiles (OPSEL picks the byte); they ride
 // two K-steps ahead in registers like the DMA.
-// LDS swizzle: 16-byte chunk ^ key(row), key = (row>>1 & 1) | (row & 1) << 1 | (row>>3 & 1) << 2: conflict-free for the 32-byte-per-lane
-// fragment reads of both the natural (activation) and the column-interleaved (weight) row order.
+// LDS swizzle: exactly the bf16 kernel's (activation rows: chunk ^ (row & 7); weight rows: chunk ^ ((row & 3) | (row >> 3 & 1) << 2)).
 #include "common.h"
 #include "avllm_internal.h"
 #include "gemm_shared.h"
@@ -137,18 +136,17 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;             // G <= ntiles (dispatcher)
     const int nt = g.K / KB;                                          // >= 2 (dispatcher)
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
-    // fragment addresses: the lane's 32 bytes are the 16-byte chunks 2 fq and 2 fq + 1 of its row, each ^ key(row)
-    const int keyA = ((fr >> 1) & 1) | ((fr & 1) << 1) | (((fr >> 3) & 1) << 2);
-    const int keyB = ((fr >> 1) & 1) | ((fr & 1) << 1) | (((fr >> 2) & 1) << 2);
+    // fragment addresses: the lane's 32 operand bytes are the 16-byte chunks fq and 4 + fq of its row (fp8.hip "Operand layout"), each ^ key(row)
+    const int keyA = fr & 7;
+    const int keyB = (fr & 3) | (((fr >> 2) & 1) << 2);
     const int rowA = lds0 + (wr * 128 + fr) * 128, rowB = lds0 + TM * 128 + (wc * 128 + 8 * (fr >> 2) + (fr & 3)) * 128;
-    const int base[4] = {rowA + (((2 * fq) ^ keyA) << 4), rowA + (((2 * fq + 1) ^ keyA) << 4),
-                         rowB + (((2 * fq) ^ keyB) << 4), rowB + (((2 * fq + 1) ^ keyB) << 4)};
+    const int base[4] = {rowA + ((fq ^ keyA) << 4), rowA + (((4 + fq) ^ keyA) << 4), rowB + ((fq ^ keyB) << 4), rowB + (((4 + fq) ^ keyB) << 4)};
     int ad[4] = {base[0] + STAGE, base[1] + STAGE, base[2] + STAGE, base[3] + STAGE};      // current buffer = 0: "other" = buffer 1
     int bo = 0;                                                      // byte offset of the current buffer
     const int mw = lds0 + wave * 8192;
-    const unsigned l3 = lane >> 3;
-    const unsigned key0 = ((l3 >> 1) & 1) | ((l3 & 1) << 1), r0 = wave * 64 + l3;
-    const unsigned ch0 = ((lane & 7) ^ key0) << 4, ch1 = ((lane & 7) ^ (key0 | 4)) << 4;      // LDS row wave*64 + 8q + l3: key bit 2 = q & 1
+    const unsigned l3 = lane >> 3, r0 = wave * 64 + l3;
+    const unsigned chA = ((lane & 7) ^ l3) << 4;                                              // activation rows: key = row & 7
+    const unsigned chB0 = ((lane & 7) ^ (l3 & 3)) << 4, chB1 = ((lane & 7) ^ ((l3 & 3) | 4)) << 4;      // weight row wave*64 + 8q + l3: key = (l3 & 3) | (q & 1) << 2
 
     unsigned vA1[8], vB1[8], vS[4];
     const uint8_t *tA1, *tB1;
@@ -161,8 +159,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const unsigned r = r0 + q * 8;
-            vA1[q] = __umul24(r < ma ? r : ma, (unsigned)g.lda) + ((q & 1) ? ch1 : ch0);
-            vB1[q] = __umul24(r < mb ? r : mb, (unsigned)g.ldb) + ((q & 1) ? ch1 : ch0);
+            vA1[q] = __umul24(r < ma ? r : ma, (unsigned)g.lda) + chA;
+            vB1[q] = __umul24(r < mb ? r : mb, (unsigned)g.ldb) + ((q & 1) ? chB1 : chB0);
         }
         tA1 = g.A + (long)lm0 * g.lda; tB1 = g.B + (long)ln0 * g.ldb;
         // scale words of this tile: byte offset of (group, fq, fr) inside a K-step's plane; group = tile's first + 2 * (wave's half) + {0, 1}

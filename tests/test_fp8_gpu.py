@@ -38,7 +38,9 @@ def test_mx_quantizer_bit_exact(dev, layout, R, K, dtype):
     deq = MX.dequantize(q.cpu(), e)
     err = (deq - x.float().cpu()).abs()
     blk = x.float().cpu().abs().reshape(R, K // 32, 32).amax(-1).repeat_interleave(32, dim=1)
-    assert bool((err <= blk * 2.0 ** -4 + 1e-30).all())          # e4m3: 3 mantissa bits, block max in [2^8, 2^9) after scaling
+    # e4m3 keeps 3 mantissa bits: half an ulp of the block's top binade is amax * 2^-4; a block maximum in (448, 512) * 2^e saturates to 448
+    # (the MX rule clamps: the exponent is floor(log2(amax)) - 8 although e4m3 tops out at 1.75 * 2^8), which costs up to amax / 8
+    assert bool((err <= blk * 2.0 ** -3 + 1e-30).all())
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (256, 256, 512), (300, 200, 384), (4096, 4096, 1024), (130, 1000, 256), (4096, 4096, 256), (5000, 2304, 768),
