@@ -41,7 +41,14 @@ def _pad_cols(w2d, kpad):
     return out
 
 
-def _enc_layers(sd, prefix_fmt, n, names, dtype, device, keep):
+def _fp8_images(w, keep):
+    """Block-scaled fp8 image of a weight matrix [N,K] (weight-side layout) -> (codes ptr, scales ptr); tensors parked in `keep`."""
+    q, s = ops.mx_quantize(w, 1)
+    keep += [q, s]
+    return q.data_ptr(), s.data_ptr()
+
+
+def _enc_layers(sd, prefix_fmt, n, names, dtype, device, keep, fp8=False):
     """Build the EncLayer array for a pre-LN encoder; `names` maps our fields to HF suffixes."""
     arr = (L.EncLayer * n)()
     for i in range(n):
@@ -66,13 +73,17 @@ def _enc_layers(sd, prefix_fmt, n, names, dtype, device, keep):
             dv = _dev(val, dtype, device)
             keep.append(dv)
             setattr(arr[i], k, dv.data_ptr())
+            if fp8 and k in ("wqkv", "wo", "w1", "w2"):
+                q8, s8 = _fp8_images(dv, keep)
+                f = {"wqkv": ("wqkv8", "sqkv8"), "wo": ("wo8", "so8"), "w1": ("w18", "s18"), "w2": ("w28", "s28")}[k]
+                setattr(arr[i], f[0], q8); setattr(arr[i], f[1], s8)
     return arr
 
 
 class WhisperEngine:
     """avllm_whisper_encoder_fwd: mel f32 [B,80,2*n_ctx] -> [B,n_ctx,d]."""
 
-    def __init__(self, sd, cfg, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, sd, cfg, dtype=torch.bfloat16, device="cuda", fp8=False):
         self.cfg, self.dtype, self.device = cfg, dtype, device
         self.keep = []
         d = cfg.d_model
@@ -90,8 +101,9 @@ class WhisperEngine:
             setattr(w, name, dv.data_ptr())
         names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
                      ln1="self_attn_layer_norm", ln2="final_layer_norm", fc1="fc1", fc2="fc2")
-        self.layers = _enc_layers(sd, "encoder.layers.{}.", cfg.layers, names, dtype, device, self.keep)
+        self.layers = _enc_layers(sd, "encoder.layers.{}.", cfg.layers, names, dtype, device, self.keep, fp8)
         w.layer = C.cast(self.layers, C.POINTER(L.EncLayer))
+        w.fp8 = int(bool(fp8))
         self.desc = w
         self.ws = Workspace(device)
 
@@ -113,7 +125,7 @@ class WhisperEngine:
 class ClipEngine:
     """avllm_clip_vision_cls_fwd: frames f32 [N,3,S,S] -> CLS of last_hidden_state [N,d] (no post_layernorm)."""
 
-    def __init__(self, sd, cfg, dtype=torch.bfloat16, device="cuda", chunk_frames=0):
+    def __init__(self, sd, cfg, dtype=torch.bfloat16, device="cuda", chunk_frames=0, fp8=False):
         sd = {k[len("vision_model."):] if k.startswith("vision_model.") else k: v for k, v in sd.items()}
         self.cfg, self.dtype, self.device = cfg, dtype, device
         self.chunk = chunk_frames
@@ -133,8 +145,9 @@ class ClipEngine:
             setattr(c, name, dv.data_ptr())
         names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.out_proj",
                      ln1="layer_norm1", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2")
-        self.layers = _enc_layers(sd, "encoder.layers.{}.", cfg.layers, names, dtype, device, self.keep)
+        self.layers = _enc_layers(sd, "encoder.layers.{}.", cfg.layers, names, dtype, device, self.keep, fp8)
         c.layer = C.cast(self.layers, C.POINTER(L.EncLayer))
+        c.fp8 = int(bool(fp8))
         self.desc = c
         self.ws = Workspace(device)
 
@@ -165,8 +178,9 @@ class LlamaEngine:
     (A [r,d], B [dout,r]; dout = d, or kv_heads*head_dim for k/v under grouped-query attention) so a layer's gradient bucket is one contiguous slice of `lora_g` for the DDP all-reduce.
     """
 
-    def __init__(self, sd, cfg, lora_cfg=None, lora_sd=None, dtype=torch.bfloat16, device="cuda", training=True):
+    def __init__(self, sd, cfg, lora_cfg=None, lora_sd=None, dtype=torch.bfloat16, device="cuda", training=True, fp8=False):
         self.cfg, self.lcfg, self.dtype, self.device, self.training = cfg, lora_cfg, dtype, device, training
+        self.fp8 = bool(fp8)
         self.keep = []
         d, f = cfg.hidden, cfg.ffn
         self.use_lora = lora_cfg is not None
@@ -195,6 +209,9 @@ class LlamaEngine:
         m.lm_head = head.data_ptr()
         if training:
             m.lm_head_t = put(head.t()).data_ptr()
+        m.fp8 = int(self.fp8)
+        if self.fp8:
+            m.lm_head8, m.slm_head8 = _fp8_images(head, self.keep)
         self.layers = (L.LlamaLayer * cfg.layers)()
         # ---- LoRA masters / grads / padded operand images
         self.per_layer = sum(r * (d + do) for do in self.douts)
@@ -224,6 +241,11 @@ class LlamaEngine:
             if training:
                 ly.wqkv_t, ly.wo_t = put(wqkv.t()).data_ptr(), put(wo.t()).data_ptr()
                 ly.wgu_t, ly.wdown_t = put(wgu.t()).data_ptr(), put(wdown.t()).data_ptr()
+            if self.fp8:
+                ly.wqkv8, ly.sqkv8 = _fp8_images(wqkv, self.keep)
+                ly.wo8, ly.so8 = _fp8_images(wo, self.keep)
+                ly.wgu8, ly.sgu8 = _fp8_images(wgu, self.keep)
+                ly.wdown8, ly.sdown8 = _fp8_images(wdown, self.keep)
             if self.use_lora:
                 es = self.img_A.element_size()
                 for j in range(4):

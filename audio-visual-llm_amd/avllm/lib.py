@@ -30,19 +30,20 @@ class GemmDesc(C.Structure):
 
 
 class EncLayer(C.Structure):
-    _fields_ = [(n, vp) for n in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")]
+    _fields_ = [(n, vp) for n in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2",
+                                  "wqkv8", "sqkv8", "wo8", "so8", "w18", "s18", "w28", "s28")]
 
 
 class Whisper(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "n_mels", "n_ctx", "k1pad")] + \
                [(n, vp) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos")] + \
-               [("layer", C.POINTER(EncLayer)), ("lnf_w", vp), ("lnf_b", vp)]
+               [("layer", C.POINTER(EncLayer)), ("lnf_w", vp), ("lnf_b", vp), ("fp8", i32)]
 
 
 class Clip(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "image", "patch", "tokens")] + \
                [("eps", f32)] + [(n, vp) for n in ("patch_w", "class_emb", "pos", "pre_ln_w", "pre_ln_b")] + \
-               [("layer", C.POINTER(EncLayer))]
+               [("layer", C.POINTER(EncLayer)), ("fp8", i32)]
 
 
 class LoraMod(C.Structure):
@@ -51,13 +52,14 @@ class LoraMod(C.Structure):
 
 class LlamaLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_w", "ln2_w", "wqkv", "wo", "wgu", "wdown", "wqkv_t", "wo_t", "wgu_t", "wdown_t")] + \
-               [("lora", LoraMod * 4)]
+               [("lora", LoraMod * 4)] + [(n, vp) for n in ("wqkv8", "sqkv8", "wo8", "so8", "wgu8", "sgu8", "wdown8", "sdown8")]
 
 
 class Llama(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "vocab", "lora_r", "kv_heads")] + \
                [(n, f32) for n in ("eps", "theta", "lora_scale", "lora_dropout")] + [("dropout_seed", C.c_uint32)] + \
-               [(n, vp) for n in ("dropout_seed_dev", "embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))]
+               [(n, vp) for n in ("dropout_seed_dev", "embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))] + \
+               [("fp8", i32), ("lm_head8", vp), ("slm_head8", vp)]
 
 
 class GemmF8Desc(C.Structure):
@@ -84,9 +86,9 @@ _SIGS = {
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),
     "avllm_gemm_tn_drop": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, C.c_uint32, f32, i32, vp], i32),
     "avllm_logmel_table_bytes": ([], C.c_size_t),
-    "avllm_logmel_table_init": ([vp], i32),
-    "avllm_logmel_workspace_bytes": ([i32], C.c_size_t),
-    "avllm_logmel": ([vp, vp, i32, i32, i64, i32, vp, vp, C.c_size_t, vp], i32),
+    "avllm_logmel_table_init": ([vp, i32], i32),
+    "avllm_logmel_workspace_bytes": ([i32, i32], C.c_size_t),
+    "avllm_logmel": ([vp, vp, i32, i32, i64, i32, i32, vp, vp, C.c_size_t, vp], i32),
     "avllm_clip_preproc_plan_bytes": ([i32, i32, i32], C.c_size_t),
     "avllm_clip_preproc_plan_init": ([vp, i32, i32, i32, vp, vp], i32),
     "avllm_clip_preproc_workspace_bytes": ([i32, i32, i32, i32], C.c_size_t),

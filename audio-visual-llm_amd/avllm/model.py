@@ -73,7 +73,13 @@ class ClipWhisperModel:
         self.modality, self.max_seq_len, self.fusion_scale = modality, max_seq_len, fusion_scale
         self.connector_type = connector_type
         precision = precision or ("bf16" if use_fp16 else "fp32")
-        self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        if precision not in ("fp32", "bf16", "fp8"):
+            raise ValueError(f"precision must be fp32|bf16|fp8, got {precision}")
+        # "fp8" (BASELINE config 5): bf16 storage, with every frozen-weight projection of the encoders and of the LLM's training forward
+        # on the block-scaled fp8 matrix pipe; attention, norms, LoRA terms, loss and the whole backward pass as in "bf16"
+        self.fp8 = precision == "fp8"
+        self.precision = precision
+        self.dtype = torch.float32 if precision == "fp32" else torch.bfloat16
         self.training = True
         self._drop_step = 0
         self._seed = int(seed or 0)
@@ -91,10 +97,10 @@ class ClipWhisperModel:
         self.clip_processor = None
         self.audio_dim, self.video_dim, self.llm_dim = cfg.whisper.d_model, cfg.clip.hidden, cfg.llama.hidden
 
-        self.whisper_engine = WhisperEngine(W["whisper"], cfg.whisper, self.dtype, device) if modality in ("audio", "both") else None
-        self.clip_engine = ClipEngine(W["clip"], cfg.clip, self.dtype, device) if modality in ("video", "both") else None
+        self.whisper_engine = WhisperEngine(W["whisper"], cfg.whisper, self.dtype, device, fp8=self.fp8) if modality in ("audio", "both") else None
+        self.clip_engine = ClipEngine(W["clip"], cfg.clip, self.dtype, device, fp8=self.fp8) if modality in ("video", "both") else None
         self.llm_engine = LlamaEngine(W["llama"], cfg.llama, cfg.lora if use_lora else None, W.get("lora"), self.dtype, device,
-                                      training=True)
+                                      training=True, fp8=self.fp8)
         self._setup_projections(W)
         self.lora_param = None
         if use_lora:

@@ -17,11 +17,12 @@ N_SAMPLES, N_MELS, N_FRAMES = 480000, 80, 3000
 
 
 class WhisperLogMel:
-    def __init__(self, device="cuda:0", normalize=True):
-        self.device, self.normalize = torch.device(device), normalize
+    def __init__(self, device="cuda:0", normalize=True, n_mels=N_MELS):
+        """n_mels: 80 (Whisper tiny..large-v2) or 128 (large-v3's feature extractor, feature_size=128)."""
+        self.device, self.normalize, self.n_mels = torch.device(device), normalize, int(n_mels)
         lib = L.load()
         self.table = torch.empty(lib.avllm_logmel_table_bytes(), dtype=torch.uint8, device=self.device)
-        L.check(lib.avllm_logmel_table_init(L.ptr(self.table)))
+        L.check(lib.avllm_logmel_table_init(L.ptr(self.table), self.n_mels))
         self._ws = None
 
     def pad_batch(self, waves):
@@ -35,7 +36,7 @@ class WhisperLogMel:
         return out
 
     def __call__(self, wave):
-        """wave: [B, n] float32 (rows zero-padded) or a list of 1-D waveforms -> [B, 80, 3000] float32 on the device."""
+        """wave: [B, n] float32 (rows zero-padded) or a list of 1-D waveforms -> [B, n_mels, 3000] float32 on the device."""
         if isinstance(wave, (list, tuple)):
             wave = self.pad_batch(wave)
         if wave.dim() == 1:
@@ -45,12 +46,12 @@ class WhisperLogMel:
         wave = wave.to(self.device, torch.float32).contiguous()
         B, n = wave.shape
         lib = L.load()
-        need = lib.avllm_logmel_workspace_bytes(B)
+        need = lib.avllm_logmel_workspace_bytes(B, self.n_mels)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out = torch.empty(B, N_MELS, N_FRAMES, dtype=torch.float32, device=self.device)
-        L.check(lib.avllm_logmel(L.ptr(self.table), L.ptr(wave), B, n, wave.stride(0), int(self.normalize), L.ptr(out), L.ptr(self._ws),
-                                 self._ws.numel(), L.stream_ptr()))
+        out = torch.empty(B, self.n_mels, N_FRAMES, dtype=torch.float32, device=self.device)
+        L.check(lib.avllm_logmel(L.ptr(self.table), L.ptr(wave), B, n, wave.stride(0), int(self.normalize), self.n_mels, L.ptr(out),
+                                 L.ptr(self._ws), self._ws.numel(), L.stream_ptr()))
         return out
 
 

@@ -80,7 +80,7 @@ class ClipWhisperTrainer:
             from .preprocess import ClipFrames, WhisperLogMel, device_collate
             if getattr(self, "_featurizers", None) is None:
                 dev = self.model.device
-                self._featurizers = (WhisperLogMel(dev), ClipFrames(dev, image=self.model.cfg.clip.image))
+                self._featurizers = (WhisperLogMel(dev, n_mels=self.model.cfg.whisper.n_mels), ClipFrames(dev, image=self.model.cfg.clip.image))
             audio, video = device_collate(batch["raw"], *self._featurizers)
             tok = self.model.tokenizer(batch["texts"], return_tensors="pt", padding=True, truncation=True, max_length=self.model.max_seq_len)
             return audio, video, batch["labels"], tok.input_ids

@@ -31,20 +31,47 @@ inline avllm_gemm_desc gemm_desc(int dtype, const void* A, long lda, const void*
     return g;
 }
 
+// ------------------------------------------------------------------ block-scaled fp8 projections (BASELINE config 5)
+// Scratch for the quantised activation of one projection input: codes [M, Kmax] + its scale image.  One quantisation serves every
+// projection that reads the same input (q, k and v of a decoder layer).
+struct F8Buf { void* q = nullptr; void* s = nullptr; };
+void carve_f8(Bump& b, F8Buf& f, long M, int kmax) {
+    f.q = b.take((size_t)M * kmax);
+    f.s = b.take(avllm_mx_scale_bytes((int)M, kmax));
+}
+inline int f8_quant(const F8Buf& f, const void* x, long ldx, int M, int K, hipStream_t st) {
+    return av_mx_quantize(x, ldx, M, K, f.q, K, f.s, 0, AV_BF16, st);
+}
+// C = act(Aq.W8^T + bias) + R with the activation already quantised into f
+inline int f8_proj(const F8Buf& f, int M, int K, const void* W8, const void* S8, int N, void* C, long ldc, const void* bias, int act, const void* R,
+                   long ldr, hipStream_t st) {
+    avllm_gemm_f8_desc d = {};
+    d.A = f.q; d.SA = f.s; d.B = W8; d.SB = S8; d.C = C; d.bias = bias; d.R = R;
+    d.lda = K; d.ldb = K; d.ldc = ldc; d.ldr = ldr; d.M = M; d.N = N; d.K = K; d.act = act;
+    return av_gemm_f8(&d, st);
+}
+
 // ------------------------------------------------------------------ encoders
-struct EncBuf { void *x, *xn, *qkv, *att, *ff; };
+struct EncBuf { void *x, *xn, *qkv, *att, *ff; F8Buf f8; };
 
 int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int heads, int ffn, int tokens, long items,
-                   float eps, int act, const EncBuf& b, bool cls_only_last, void* cls_out, void* xc, void* xcn, hipStream_t st) {
+                   float eps, int act, const EncBuf& b, bool cls_only_last, void* cls_out, void* xc, void* xcn, hipStream_t st, bool fp8 = false) {
     const long M = items * tokens;
     const int hd = d / heads;
     const size_t es = av_dtype_size(dtype);
     for (int l = 0; l < layers; ++l) {
         const avllm_enc_layer& P = L[l];
+        AV_CHECK_ARG(!fp8 || (P.wqkv8 && P.sqkv8 && P.wo8 && P.so8 && P.w18 && P.s18 && P.w28 && P.s28), "encoder layer %d: fp8 mode without fp8 weight images", l);
         AV_TRY(av_layernorm(b.x, P.ln1_w, P.ln1_b, b.xn, M, d, eps, dtype, st));
-        avllm_gemm_desc g = gemm_desc(dtype, b.xn, d, P.wqkv, d, b.qkv, 3 * d, (int)M, 3 * d, d);
-        g.bias = P.bqkv;
-        AV_TRY(av_gemm(&g, st));
+        avllm_gemm_desc g;
+        if (fp8) {
+            AV_TRY(f8_quant(b.f8, b.xn, d, (int)M, d, st));
+            AV_TRY(f8_proj(b.f8, (int)M, d, P.wqkv8, P.sqkv8, 3 * d, b.qkv, 3 * d, P.bqkv, AV_ACT_NONE, nullptr, 0, st));
+        } else {
+            g = gemm_desc(dtype, b.xn, d, P.wqkv, d, b.qkv, 3 * d, (int)M, 3 * d, d);
+            g.bias = P.bqkv;
+            AV_TRY(av_gemm(&g, st));
+        }
         const char* qkv = (const char*)b.qkv;
         AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, b.att, nullptr, (int)items, tokens, tokens,
                                 heads, hd, 3 * d, 3 * d, 3 * d, d, 1.0f / sqrtf((float)hd), 0, dtype, 0, st));
@@ -61,6 +88,16 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
             g.bias = P.b2; g.R = xc; g.ldr = d;
             AV_TRY(av_gemm(&g, st));
             return AV_OK;
+        }
+        if (fp8) {      // the CLS-only last block above stays bf16: a handful of rows
+            AV_TRY(f8_quant(b.f8, b.att, d, (int)M, d, st));
+            AV_TRY(f8_proj(b.f8, (int)M, d, P.wo8, P.so8, d, b.x, d, P.bo, AV_ACT_NONE, b.x, d, st));
+            AV_TRY(av_layernorm(b.x, P.ln2_w, P.ln2_b, b.xn, M, d, eps, dtype, st));
+            AV_TRY(f8_quant(b.f8, b.xn, d, (int)M, d, st));
+            AV_TRY(f8_proj(b.f8, (int)M, d, P.w18, P.s18, ffn, b.ff, ffn, P.b1, act, nullptr, 0, st));
+            AV_TRY(f8_quant(b.f8, b.ff, ffn, (int)M, ffn, st));
+            AV_TRY(f8_proj(b.f8, (int)M, ffn, P.w28, P.s28, d, b.x, d, P.b2, AV_ACT_NONE, b.x, d, st));
+            continue;
         }
         g = gemm_desc(dtype, b.att, d, P.wo, d, b.x, d, (int)M, d, d);
         g.bias = P.bo; g.R = b.x; g.ldr = d;
@@ -88,6 +125,7 @@ void carve_whisper(const avllm_whisper* w, int B, Bump& b, WhisperWs& s) {
     s.e.qkv = b.take((size_t)M * 3 * w->d * es);
     s.e.att = b.take((size_t)M * w->d * es);
     s.e.ff = b.take((size_t)M * w->ffn * es);
+    if (w->fp8) carve_f8(b, s.e.f8, M, w->ffn > w->d ? w->ffn : w->d);
 }
 
 struct ClipWs { void* cols; EncBuf e; void *xc, *xcn; };
@@ -104,6 +142,7 @@ void carve_clip(const avllm_clip* c, int N, Bump& b, ClipWs& s, int& kpad) {
     s.e.ff = b.take((size_t)M * c->ffn * es);
     s.xc = b.take((size_t)N * c->d * es);
     s.xcn = b.take((size_t)N * c->d * es);
+    if (c->fp8) carve_f8(b, s.e.f8, M, c->ffn > c->d ? c->ffn : c->d);
 }
 
 // ------------------------------------------------------------------ llama
@@ -123,6 +162,7 @@ struct LlamaTrainWs {
     float *rstd_f, *row_lse, *delta, *rope_tab;
     // backward scratch
     void *dres, *dxn, *dgu, *dhmid, *dqkv, *datt, *dtqkv, *dto;
+    F8Buf f8;                // fp8 mode: the quantised input of the projection being computed
 };
 
 void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs& w, void** resid, LlamaLayerAct* act) {
@@ -161,6 +201,7 @@ void carve_llama_train(const avllm_llama* m, int B, int S, Bump& b, LlamaTrainWs
     w.datt = b.take((size_t)M * d * es);
     w.dtqkv = b.take((size_t)M * 3 * AVLLM_LORA_PAD * es);
     w.dto = b.take((size_t)M * AVLLM_LORA_PAD * es);
+    if (m->fp8) carve_f8(b, w.f8, M, f > d ? f : d);
 }
 
 int check_llama(const avllm_llama* m) {
@@ -198,6 +239,18 @@ int lora_proj(const avllm_llama* m, const void* x, long ldx, const void* W, long
     return av_gemm(&g, st);
 }
 
+// fp8 mode: the adapter term alone, y += scale * (dropout(x) A^T) B^T on top of a base product already in y (bf16, rank-side GEMM + K=64 GEMM)
+int lora_add(const avllm_llama* m, const void* x, long ldx, int K, int N, const avllm_lora_mod& lm, void* t, long ldt, void* y, long ldy, int M,
+             hipStream_t st, const void* xl, uint32_t a_seed, float a_p) {
+    if (!lm.A_pad) return AV_OK;
+    avllm_gemm_desc g = gemm_desc(m->dtype, xl ? xl : x, xl ? (long)K : ldx, lm.A_pad, K, t, ldt, M, AVLLM_LORA_PAD, K);
+    g.alpha = m->lora_scale; g.a_drop_seed = a_seed; g.a_drop_p = a_p; g.seed_dev = m->dropout_seed_dev; g.n_valid = m->lora_r;
+    AV_TRY(av_gemm(&g, st));
+    g = gemm_desc(m->dtype, t, ldt, lm.B_pad, AVLLM_LORA_PAD, y, ldy, M, N, AVLLM_LORA_PAD);
+    g.R = y; g.ldr = ldy;
+    return av_gemm(&g, st);
+}
+
 }  // namespace
 
 // =============================================================================================== Whisper
@@ -228,8 +281,9 @@ extern "C" int avllm_whisper_encoder_fwd(const avllm_whisper* w, const float* me
     g = gemm_desc(dt, s.cols2, 3 * d, w->conv2_w, 3 * d, s.e.x, d, (int)M, d, 3 * d);
     g.bias = w->conv2_b; g.act = AV_ACT_GELU; g.R = w->pos; g.ldr = d; g.r_mod = w->n_ctx;
     AV_TRY(av_gemm(&g, st));
+    AV_CHECK_ARG(!w->fp8 || (dt == AV_BF16 && d % 128 == 0 && w->ffn % 128 == 0), "whisper: fp8 needs bf16 activations and widths that are multiples of 128");
     AV_TRY(encoder_layers(dt, w->layer, w->layers, d, w->heads, w->ffn, w->n_ctx, B, 1e-5f, AV_ACT_GELU, s.e, false, nullptr,
-                          nullptr, nullptr, st));
+                          nullptr, nullptr, st, w->fp8 != 0));
     return av_layernorm(s.e.x, w->lnf_w, w->lnf_b, out, M, d, 1e-5f, dt, st);
 }
 
@@ -262,8 +316,9 @@ extern "C" int avllm_clip_vision_cls_fwd(const avllm_clip* c, const float* frame
     AV_TRY(av_gemm(&g, st));
     AV_TRY(av_clip_cls_rows(c->class_emb, c->pos, s.e.xn, N, c->tokens, d, dt, st));
     AV_TRY(av_layernorm(s.e.xn, c->pre_ln_w, c->pre_ln_b, s.e.x, (long)N * c->tokens, d, c->eps, dt, st));
+    AV_CHECK_ARG(!c->fp8 || (dt == AV_BF16 && d % 128 == 0 && c->ffn % 128 == 0), "clip: fp8 needs bf16 activations and widths that are multiples of 128");
     return encoder_layers(dt, c->layer, c->layers, d, c->heads, c->ffn, c->tokens, N, c->eps, AV_ACT_QUICK_GELU, s.e, true, cls,
-                          s.xc, s.xcn, st);
+                          s.xc, s.xcn, st, c->fp8 != 0);
 }
 
 // =============================================================================================== Llama train
@@ -296,14 +351,27 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     const bool drop = m->lora_dropout > 0.f;
     // bf16 (MFMA kernels): masks are generated inside the rank-side GEMMs; fp32 parity mode materialises dropout(x)
     const bool fuse_drop = drop && m->dtype == AV_BF16 && d % 256 == 0 && m->lora_r <= 16;
+    const bool fp8 = m->fp8 != 0;
+    AV_CHECK_ARG(!fp8 || (dt == AV_BF16 && d % 128 == 0 && f % 128 == 0 && m->vocab % 8 == 0 && m->lm_head8 && m->slm_head8),
+                 "llama: fp8 needs bf16 activations, d and ffn multiples of 128 and the fp8 weight images");
     for (int l = 0; l < m->layers; ++l) {
         const avllm_llama_layer& P = m->layer[l];
         LlamaLayerAct& a = act[l];
         AV_TRY(av_rmsnorm_fwd(resid[l], P.ln1_w, a.xn1, a.rstd1, M, d, m->eps, dt, st));
+        if (fp8) {      // one fp8 product for q|k|v (one quantisation of the normed input), adapters added on top
+            AV_CHECK_ARG(P.wqkv8 && P.sqkv8 && P.wo8 && P.so8 && P.wgu8 && P.sgu8 && P.wdown8 && P.sdown8, "llama layer %d: fp8 mode without fp8 weight images", l);
+            AV_TRY(f8_quant(w.f8, a.xn1, d, M, d, st));
+            AV_TRY(f8_proj(w.f8, M, d, P.wqkv8, P.sqkv8, qw, a.qkv, qw, nullptr, AV_ACT_NONE, nullptr, 0, st));
+        }
         for (int j = 0; j < 3; ++j) {
             const void* xl = nullptr;
             const uint32_t sj = m->dropout_seed + 4u * l + j;
             if (drop && !fuse_drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, sj, m->lora_dropout, dt, st, m->dropout_seed_dev)); xl = w.xd; }
+            if (fp8) {
+                AV_TRY(lora_add(m, a.xn1, d, d, llama_wid(m, j), P.lora[j], (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
+                                (char*)a.qkv + (size_t)llama_off(m, j) * es, qw, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
+                continue;
+            }
             AV_TRY(lora_proj(m, a.xn1, d, (const char*)P.wqkv + (size_t)llama_off(m, j) * d * es, d, d, llama_wid(m, j), P.lora[j],
                              (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
                              (char*)a.qkv + (size_t)llama_off(m, j) * es, qw, nullptr, 0, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
@@ -316,10 +384,23 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
             const void* xl = nullptr;
             const uint32_t so = m->dropout_seed + 4u * l + 3;
             if (drop && !fuse_drop && P.lora[3].A_pad) { AV_TRY(av_dropout(a.att, w.xd, M, d, so, m->lora_dropout, dt, st, m->dropout_seed_dev)); xl = w.xd; }
+            if (fp8) {
+                AV_TRY(f8_quant(w.f8, a.att, d, M, d, st));
+                AV_TRY(f8_proj(w.f8, M, d, P.wo8, P.so8, d, a.h1, d, nullptr, AV_ACT_NONE, resid[l], d, st));
+                AV_TRY(lora_add(m, a.att, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, M, st, xl, so, fuse_drop ? m->lora_dropout : 0.f));
+            } else
             AV_TRY(lora_proj(m, a.att, d, P.wo, d, d, d, P.lora[3], a.to, AVLLM_LORA_PAD, a.h1, d, resid[l], d, M, st, xl, so,
                              fuse_drop ? m->lora_dropout : 0.f));
         }
         AV_TRY(av_rmsnorm_fwd(a.h1, P.ln2_w, w.xn2, a.rstd2, M, d, m->eps, dt, st));
+        if (fp8) {
+            AV_TRY(f8_quant(w.f8, w.xn2, d, M, d, st));
+            AV_TRY(f8_proj(w.f8, M, d, P.wgu8, P.sgu8, 2 * f, a.gu, 2 * f, nullptr, AV_ACT_NONE, nullptr, 0, st));
+            AV_TRY(av_swiglu_fwd(a.gu, w.hmid, M, f, dt, st));
+            AV_TRY(f8_quant(w.f8, w.hmid, f, M, f, st));
+            AV_TRY(f8_proj(w.f8, M, f, P.wdown8, P.sdown8, d, resid[l + 1], d, nullptr, AV_ACT_NONE, a.h1, d, st));
+            continue;
+        }
         avllm_gemm_desc g = gemm_desc(dt, w.xn2, d, P.wgu, d, a.gu, 2 * f, M, 2 * f, d);
         AV_TRY(av_gemm(&g, st));
         AV_TRY(av_swiglu_fwd(a.gu, w.hmid, M, f, dt, st));
@@ -329,6 +410,10 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     }
     AV_TRY(av_rmsnorm_fwd(resid[m->layers], m->norm_w, w.xf, w.rstd_f, M, d, m->eps, dt, st));
     avllm_gemm_desc g = gemm_desc(dt, w.xf, d, m->lm_head, d, w.logits, m->vocab, M, m->vocab, d);
+    if (fp8) {
+        AV_TRY(f8_quant(w.f8, w.xf, d, M, d, st));
+        AV_TRY(f8_proj(w.f8, M, d, m->lm_head8, m->slm_head8, m->vocab, w.logits, m->vocab, nullptr, AV_ACT_NONE, nullptr, 0, st));
+    } else
     AV_TRY(av_gemm(&g, st));
     if (logits_out) AV_HIP(hipMemcpyAsync(logits_out, w.logits, (size_t)M * m->vocab * es, hipMemcpyDeviceToDevice, st));
     if (labels) AV_TRY(av_ce_fwd(w.logits, m->vocab, labels, B, S, m->vocab, w.row_lse, loss_sum, count, dt, st));

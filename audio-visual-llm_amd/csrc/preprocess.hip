@@ -18,13 +18,14 @@
 
 namespace {
 
-constexpr int NFFT = 400, HOP = 160, NBIN = 201, NMEL = 80, NSAMP = 480000, NFRAME = 3000, MELW = 32;
+constexpr int NFFT = 400, HOP = 160, NBIN = 201, NMEL_MAX = 128, NSAMP = 480000, NFRAME = 3000, MELW = 32;      // 80 mel bins (Whisper tiny..large-v2) or 128 (large-v3)
 constexpr int FR = 8;                        // frames per workgroup
 
 struct LogmelTab {
     double win[NFFT], cs[NFFT], sn[NFFT];
-    double w[NMEL][MELW];
-    int lo[NMEL], cnt[NMEL];
+    double w[NMEL_MAX][MELW];
+    int lo[NMEL_MAX], cnt[NMEL_MAX];
+    int n_mels;
 };
 
 __global__ __launch_bounds__(256) void logmel_frames_kernel(const LogmelTab* __restrict__ tab, const float* __restrict__ wave, long ld,
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void logmel_frames_kernel(const LogmelTab* __r
     __shared__ double cs[NFFT], sn[NFFT];
     __shared__ double pw[FR][NBIN + 3];
     const int b = blockIdx.y, f0 = blockIdx.x * FR, tid = threadIdx.x;
+    const int NMEL = tab->n_mels;
     const float* x = wave + (long)b * ld;
     for (int i = tid; i < NFFT; i += 256) { cs[i] = tab->cs[i]; sn[i] = tab->sn[i]; }
     for (int i = tid; i < FR * NFFT; i += 256) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void logmel_frames_kernel(const LogmelTab* __r
 }
 
 // per clip: clamp to (max - 8), (x + 4) / 4 in float32 as HF does, then (optionally) F.layer_norm over the whole [80,3000]
-__global__ __launch_bounds__(1024) void logmel_finish_kernel(const float* __restrict__ logspec, float* __restrict__ out, int normalize) {
+__global__ __launch_bounds__(1024) void logmel_finish_kernel(const float* __restrict__ logspec, float* __restrict__ out, int normalize, int NMEL) {
     __shared__ double red[16];
     __shared__ float redf[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -306,8 +308,10 @@ std::map<const void*, std::array<int, 3>> g_plans;
 // =============================================================================================== C ABI
 extern "C" size_t avllm_logmel_table_bytes(void) { return (sizeof(LogmelTab) + 255) & ~(size_t)255; }
 
-extern "C" int avllm_logmel_table_init(void* table_dev) {
+extern "C" int avllm_logmel_table_init(void* table_dev, int32_t n_mels) {
     AV_CHECK_ARG(table_dev, "logmel_table_init: null");
+    AV_CHECK_ARG(n_mels == 80 || n_mels == 128, "logmel_table_init: n_mels=%d (Whisper uses 80 or 128)", n_mels);
+    const int NMEL = n_mels;
     std::vector<char> buf(sizeof(LogmelTab), 0);
     LogmelTab* t = (LogmelTab*)buf.data();
     const double pi = 3.14159265358979323846;
@@ -319,7 +323,7 @@ extern "C" int avllm_logmel_table_init(void* table_dev) {
     // audio_utils.mel_filter_bank(201, 80, 0, 8000, 16000, norm="slaney", mel_scale="slaney")
     auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4)) : 3.0 * f / 200.0; };
     auto mel2hz = [](double m) { return m >= 15.0 ? 1000.0 * std::exp((std::log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0; };
-    double ff[NMEL + 2];
+    double ff[NMEL_MAX + 2];
     const double m0 = hz2mel(0.0), m1 = hz2mel(8000.0), step = (m1 - m0) / (NMEL + 1);
     for (int i = 0; i < NMEL + 2; ++i) ff[i] = mel2hz(i == NMEL + 1 ? m1 : m0 + step * i);      // np.linspace end point is exact
     const double fstep = 8000.0 / (NBIN - 1);
@@ -340,22 +344,24 @@ extern "C" int avllm_logmel_table_init(void* table_dev) {
         }
         t->lo[m] = lo < 0 ? 0 : lo; t->cnt[m] = cnt;
     }
+    t->n_mels = NMEL;
     AV_HIP(hipMemcpy(table_dev, buf.data(), sizeof(LogmelTab), hipMemcpyHostToDevice));
     return AV_OK;
 }
 
-extern "C" size_t avllm_logmel_workspace_bytes(int32_t B) { return (size_t)B * NMEL * NFRAME * 4 + 256; }
+extern "C" size_t avllm_logmel_workspace_bytes(int32_t B, int32_t n_mels) { return (size_t)B * n_mels * NFRAME * 4 + 256; }
 
-extern "C" int avllm_logmel(const void* table, const float* wave, int32_t B, int32_t n, int64_t ld, int32_t normalize, float* out,
+extern "C" int avllm_logmel(const void* table, const float* wave, int32_t B, int32_t n, int64_t ld, int32_t normalize, int32_t n_mels, float* out,
                             void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AV_CHECK_ARG(table && wave && out && ws && B > 0 && n >= 0 && ld >= n, "logmel: null/empty (B=%d n=%d ld=%ld)", B, n, (long)ld);
-    AV_CHECK_ARG(ws_bytes >= avllm_logmel_workspace_bytes(B), "logmel: workspace %zu < %zu bytes", ws_bytes, avllm_logmel_workspace_bytes(B));
+    AV_CHECK_ARG(n_mels == 80 || n_mels == 128, "logmel: n_mels=%d must match the table (80 or 128)", n_mels);
+    AV_CHECK_ARG(ws_bytes >= avllm_logmel_workspace_bytes(B, n_mels), "logmel: workspace %zu < %zu bytes", ws_bytes, avllm_logmel_workspace_bytes(B, n_mels));
     if (n > NSAMP) n = NSAMP;                                  // truncation=True, max_length = 30 s
     float* logspec = (float*)ws;
     hipLaunchKernelGGL(logmel_frames_kernel, dim3(NFRAME / FR, B), dim3(256), 0, st, (const LogmelTab*)table, wave, (long)ld, n, logspec);
     AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(logmel_finish_kernel, dim3(B), dim3(1024), 0, st, logspec, out, normalize);
+    hipLaunchKernelGGL(logmel_finish_kernel, dim3(B), dim3(1024), 0, st, logspec, out, normalize, n_mels);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -29,6 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK = 2.5e15       # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+MFMA_FP8_PEAK = 5.0e15        # dense, same table "Peak FP8 MFMA" (block-scaled forms)
 FLOP_PER_CLIP = 11.64e12      # Whisper 0.344 + CLIP 4.391 + connectors 0.010 + LLM fwd 3.417 + bwd 3.451 + LoRA 0.026 TF
 
 
@@ -74,7 +75,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=125)
     ap.add_argument("--max-seq-len", type=int, default=512)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="bf16", help="bf16 (BASELINE configs[1..3]) | fp32 | fp8 (BASELINE configs[4]: block-scaled fp8 on the frozen "
+                    "projections of the forward pass; use with --whisper openai/whisper-large-v3 --clip openai/clip-vit-large-patch14 "
+                    "--llm mistralai/Mistral-7B-v0.1 --frames 750)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the captured hipGraph")
@@ -180,10 +183,13 @@ def main():
                        "final_loss": round(final_loss, 5), "launch": "hipGraph replay" if use_graph else "eager"},
         }
         frac_e2e = value / world * FLOP_PER_CLIP / MFMA_BF16_PEAK
+        peak = MFMA_FP8_PEAK if args.precision == "fp8" else MFMA_BF16_PEAK
         if timing and prof[2] > 0:
             ach = prof[1] / (prof[0] * 1e-3) / 1e12           # TFLOP/s over the GEMM launches only
-            out["roofline"] = {"bound": "mfma", "kernel": "avllm_gemm launches: every dense projection (dominant: gemm_bf16_wp_kernel, persistent 256x256 tiles, 4 waves x 128x128)", "achieved": round(ach, 2),
-                               "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / (MFMA_BF16_PEAK / 1e12), 4),
+            kern = ("avllm_gemm launches: every dense projection (dominant: gemm_bf16_wp_kernel, persistent 256x256 tiles, 4 waves x 128x128)" if args.precision != "fp8" else
+                    "every dense projection launch: forward frozen-weight projections on gemm_f8_wp_kernel (block-scaled fp8, persistent 256x256 tiles), backward dX and LoRA GEMMs on the bf16 kernels; priced against the fp8 peak")
+            out["roofline"] = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2),
+                               "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
                                "traffic": pmc_traffic_bytes(), "traffic_note": "HBM bytes per 256x256-tile GEMM launch, launch-weighted over the 256x256 kernels (FETCH_SIZE x2-corrected + WRITE_SIZE) from the separate rocprofv3 --pmc passes summarised in " + PMC_SUMMARY,
                                "launches_per_step": int(prof[2] / sampled), "timed_steps": f"{sampled} of {args.steps} (every {TIMING_EVERY}th; launched eagerly, the others replay the captured hipGraph)" if use_graph else f"{sampled} of {args.steps} (every {TIMING_EVERY}th)",
                                "avg_launch_us": round(1000 * prof[0] / prof[2], 2), "gemm_ms_per_step": round(prof[0] / sampled, 3),

@@ -219,10 +219,10 @@ int avllm_lora_pack_batch(const avllm_lora_pack_item* items_dev, int32_t n, int3
  * max-8, (x+4)/4 (WhisperFeatureExtractor, feature_extraction_whisper.py:105-133); normalize != 0 adds the dataset's
  * whole-tensor layer norm (simple_dataset.py:181-183). */
 size_t avllm_logmel_table_bytes(void);
-int avllm_logmel_table_init(void* table_dev);
-size_t avllm_logmel_workspace_bytes(int32_t B);
-int avllm_logmel(const void* table, const float* wave, int32_t B, int32_t n, int64_t ld, int32_t normalize, float* out,
-                 void* ws, size_t ws_bytes, void* stream);
+int avllm_logmel_table_init(void* table_dev, int32_t n_mels);      /* n_mels: 80 (Whisper tiny..large-v2) or 128 (large-v3: feature_size=128) */
+size_t avllm_logmel_workspace_bytes(int32_t B, int32_t n_mels);
+int avllm_logmel(const void* table, const float* wave, int32_t B, int32_t n, int64_t ld, int32_t normalize, int32_t n_mels, float* out,
+                 void* ws, size_t ws_bytes, void* stream);      /* out f32 [B, n_mels, 3000]; n_mels must be the table's */
 
 /* CLIPImageProcessor on device: frames u8 [N,H,W,3] RGB -> out [N,3,image,image] (dtype f32 or bf16): resize so the shorter
  * edge is `image` (Pillow BICUBIC, bit-exact 8-bit fixed point: horizontal pass, uint8, vertical pass), centre crop, x/255,
@@ -249,6 +249,9 @@ typedef struct avllm_enc_layer {
     const void *wo, *bo;
     const void *ln2_w, *ln2_b;
     const void *w1, *b1, *w2, *b2;
+    /* fp8 mode (avllm_whisper.fp8 / avllm_clip.fp8 != 0): the four weight matrices once more as block-scaled fp8 (avllm_mx_quantize layout 1):
+     * codes [rows, K] and scale images.  The bf16 matrices above are then unused by the encoder forward. */
+    const void *wqkv8, *sqkv8, *wo8, *so8, *w18, *s18, *w28, *s28;
 } avllm_enc_layer;
 
 typedef struct avllm_whisper {
@@ -258,6 +261,7 @@ typedef struct avllm_whisper {
     const void* pos;                 /* [n_ctx,d] */
     const avllm_enc_layer* layer;    /* host array [layers] */
     const void *lnf_w, *lnf_b;
+    int32_t fp8;                     /* 1: layer projections run on the block-scaled fp8 matrix pipe (dtype must be AVLLM_BF16) */
 } avllm_whisper;
 size_t avllm_whisper_workspace_bytes(const avllm_whisper* w, int32_t B);
 /* ClipWhisperModel.encode_audio minus the connector (clip_whisper_model.py:1067-1104 ->
@@ -272,6 +276,7 @@ typedef struct avllm_clip {
     const void *class_emb, *pos;     /* [d], [tokens,d] */
     const void *pre_ln_w, *pre_ln_b;
     const avllm_enc_layer* layer;    /* host array [layers] */
+    int32_t fp8;                     /* as avllm_whisper.fp8 */
 } avllm_clip;
 size_t avllm_clip_workspace_bytes(const avllm_clip* c, int32_t N);
 /* ClipWhisperModel.encode_video minus the connector (clip_whisper_model.py:1108-1142 -> CLIPVisionModel.forward,
@@ -297,6 +302,9 @@ typedef struct avllm_llama_layer {
     const void *wgu_t;               /* [d,2f] */
     const void *wdown_t;             /* [f,d] */
     avllm_lora_mod lora[4];          /* q,k,v,o */
+    /* fp8 mode (avllm_llama.fp8 != 0): forward-pass images of the four frozen matrices (avllm_mx_quantize layout 1).  The backward pass keeps
+     * using the bf16 transposed images: gradients are not quantised. */
+    const void *wqkv8, *sqkv8, *wo8, *so8, *wgu8, *sgu8, *wdown8, *sdown8;
 } avllm_llama_layer;
 
 typedef struct avllm_llama {
@@ -312,6 +320,10 @@ typedef struct avllm_llama {
     const void* lm_head;             /* [vocab,d] */
     const void* lm_head_t;           /* [d,vocab] (training) */
     const avllm_llama_layer* layer;  /* host array [layers] */
+    int32_t fp8;                     /* 1: the frozen projections of avllm_llama_lora_fwd_loss (q/k/v/o base terms, gate/up, down, lm_head) run on
+                                      * the block-scaled fp8 matrix pipe (BASELINE config 5); LoRA terms, attention, norms and the whole
+                                      * backward pass stay bf16 */
+    const void *lm_head8, *slm_head8;
 } avllm_llama;
 
 size_t avllm_llama_train_workspace_bytes(const avllm_llama* m, int32_t B, int32_t S);

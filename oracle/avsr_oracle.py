@@ -16,6 +16,48 @@ import torch
 import torch.nn.functional as F
 
 
+# --------------------------------------------------------------------------- block-scaled fp8 mode (BASELINE config 5)
+# The reference has no fp8 mode; the HIP path's `precision="fp8"` runs the frozen-weight projections of the encoders and of the LLM's
+# TRAINING forward on the fp8 matrix pipe (oracle/mxfp8.py restates that arithmetic).  `fp8_mode()` switches the projections below to it:
+# `_proj_enc` = encoder q/k/v/out/fc1/fc2, `_proj_llm` = decoder q/k/v/o base terms, gate/up/down and lm_head of the training forward.
+_FP8 = {"enc": False, "llm": False}
+
+
+class fp8_mode:
+    def __init__(self, encoders=True, llm=True):
+        self.new = {"enc": encoders, "llm": llm}
+
+    def __enter__(self):
+        self.old = dict(_FP8)
+        _FP8.update(self.new)
+
+    def __exit__(self, *a):
+        _FP8.update(self.old)
+
+
+class _LinearFp8(torch.autograd.Function):
+    """y = fq(bf16(x)) fq(W)^T; backward dx = dy W: the HIP backward pass multiplies by the bf16 weights, gradients are not quantised."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from . import mxfp8
+        ctx.save_for_backward(w)
+        return mxfp8.linear_fp8(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        return dy @ w, None
+
+
+def _proj_enc(x, w):
+    return _LinearFp8.apply(x, w) if _FP8["enc"] else x @ w.T
+
+
+def _proj_llm(x, w):
+    return _LinearFp8.apply(x, w) if _FP8["llm"] else x @ w.T
+
+
 # --------------------------------------------------------------------------- primitives
 def layer_norm(x, w, b, eps=1e-5):
     mu = x.mean(-1, keepdim=True)
@@ -59,15 +101,15 @@ def whisper_encoder(sd, c, mel):
     for i in range(c.layers):
         L = f"encoder.layers.{i}."
         h = layer_norm(x, sd[L + "self_attn_layer_norm.weight"], sd[L + "self_attn_layer_norm.bias"])
-        q = (h @ sd[L + "self_attn.q_proj.weight"].T + sd[L + "self_attn.q_proj.bias"]) * (hd ** -0.5)
-        k = h @ sd[L + "self_attn.k_proj.weight"].T
-        v = h @ sd[L + "self_attn.v_proj.weight"].T + sd[L + "self_attn.v_proj.bias"]
+        q = (_proj_enc(h, sd[L + "self_attn.q_proj.weight"]) + sd[L + "self_attn.q_proj.bias"]) * (hd ** -0.5)
+        k = _proj_enc(h, sd[L + "self_attn.k_proj.weight"])
+        v = _proj_enc(h, sd[L + "self_attn.v_proj.weight"]) + sd[L + "self_attn.v_proj.bias"]
         sp = lambda t: t.view(B, T, H, hd).transpose(1, 2)
         a = softmax_attention(sp(q), sp(k), sp(v), 1.0, causal=False)
-        x = x + (a @ sd[L + "self_attn.out_proj.weight"].T + sd[L + "self_attn.out_proj.bias"])
+        x = x + (_proj_enc(a, sd[L + "self_attn.out_proj.weight"]) + sd[L + "self_attn.out_proj.bias"])
         h = layer_norm(x, sd[L + "final_layer_norm.weight"], sd[L + "final_layer_norm.bias"])
-        h = gelu_erf(h @ sd[L + "fc1.weight"].T + sd[L + "fc1.bias"])
-        x = x + (h @ sd[L + "fc2.weight"].T + sd[L + "fc2.bias"])
+        h = gelu_erf(_proj_enc(h, sd[L + "fc1.weight"]) + sd[L + "fc1.bias"])
+        x = x + (_proj_enc(h, sd[L + "fc2.weight"]) + sd[L + "fc2.bias"])
     return layer_norm(x, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"])
 
 
@@ -90,15 +132,17 @@ def clip_vision_cls(sd, c, frames):
     for i in range(c.layers):
         L = f"encoder.layers.{i}."
         h = layer_norm(x, sd[L + "layer_norm1.weight"], sd[L + "layer_norm1.bias"], c.eps)
-        q = h @ sd[L + "self_attn.q_proj.weight"].T + sd[L + "self_attn.q_proj.bias"]
-        k = h @ sd[L + "self_attn.k_proj.weight"].T + sd[L + "self_attn.k_proj.bias"]
-        v = h @ sd[L + "self_attn.v_proj.weight"].T + sd[L + "self_attn.v_proj.bias"]
+        # fp8 mode: the last block's out_proj / MLP run on the CLS rows only, in bf16 (csrc/engine.hip encoder_layers)
+        pe_ = _proj_enc if i + 1 < c.layers else (lambda xx, ww: xx @ ww.T)
+        q = _proj_enc(h, sd[L + "self_attn.q_proj.weight"]) + sd[L + "self_attn.q_proj.bias"]
+        k = _proj_enc(h, sd[L + "self_attn.k_proj.weight"]) + sd[L + "self_attn.k_proj.bias"]
+        v = _proj_enc(h, sd[L + "self_attn.v_proj.weight"]) + sd[L + "self_attn.v_proj.bias"]
         sp = lambda t: t.view(N, T, H, hd).transpose(1, 2)
         a = softmax_attention(sp(q), sp(k), sp(v), hd ** -0.5, causal=False)
-        x = x + (a @ sd[L + "self_attn.out_proj.weight"].T + sd[L + "self_attn.out_proj.bias"])
+        x = x + (pe_(a, sd[L + "self_attn.out_proj.weight"]) + sd[L + "self_attn.out_proj.bias"])
         h = layer_norm(x, sd[L + "layer_norm2.weight"], sd[L + "layer_norm2.bias"], c.eps)
-        h = quick_gelu(h @ sd[L + "mlp.fc1.weight"].T + sd[L + "mlp.fc1.bias"])
-        x = x + (h @ sd[L + "mlp.fc2.weight"].T + sd[L + "mlp.fc2.bias"])
+        h = quick_gelu(pe_(h, sd[L + "mlp.fc1.weight"]) + sd[L + "mlp.fc1.bias"])
+        x = x + (pe_(h, sd[L + "mlp.fc2.weight"]) + sd[L + "mlp.fc2.bias"])
     return x[:, 0]
 
 
@@ -214,7 +258,7 @@ def lora_linear(x, w, lora, key, scale, masks=None):
     """peft lora.Linear: W x + scale * B(A dropout(x)).  `masks[key]` (same shape as x, already scaled by 1/(1-p)) is the
     dropout mask of this module; None = eval / p=0.  Reference wrap: clip_whisper_model.py:961-1005.
     Parity unpinned against real peft (not installed)."""
-    y = x @ w.T
+    y = _proj_llm(x, w)
     if lora is not None and (key + ".lora_A") in lora:
         xl = x * masks[key].view_as(x) if masks is not None and key in masks else x
         y = y + scale * ((xl @ lora[key + ".lora_A"].T) @ lora[key + ".lora_B"].T)
@@ -248,9 +292,9 @@ def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0, masks=None):
         a = softmax_attention(q, k, v, hd ** -0.5, causal=True)
         x = x + lora_linear(a, sd[L + "self_attn.o_proj.weight"], lora, K + "o_proj", scale, masks)
         h = rms_norm(x, sd[L + "post_attention_layernorm.weight"], c.eps)
-        g = h @ sd[L + "mlp.gate_proj.weight"].T
-        u = h @ sd[L + "mlp.up_proj.weight"].T
-        x = x + (F.silu(g) * u) @ sd[L + "mlp.down_proj.weight"].T
+        g = _proj_llm(h, sd[L + "mlp.gate_proj.weight"])
+        u = _proj_llm(h, sd[L + "mlp.up_proj.weight"])
+        x = x + _proj_llm(F.silu(g) * u, sd[L + "mlp.down_proj.weight"])
     return rms_norm(x, sd["model.norm.weight"], c.eps)
 
 
@@ -299,7 +343,7 @@ def train_step_grads(W, cfg, audio, video, prompt, labels, masks=None):
         x, mask, lab = prepare_llm_inputs(W, cfg, audio, video, prompt, labels, training=True)
     lora = {k: v.clone().requires_grad_(True) for k, v in W["lora"].items()}
     h = llama_hidden(W["llama"], lora, cfg.llama, cfg.lora, x, masks=masks)
-    logits = h @ W["llama"]["lm_head.weight"].T
+    logits = _proj_llm(h, W["llama"]["lm_head.weight"])
     loss = causal_lm_loss(logits, lab)
     loss.backward()
     return loss.detach(), logits.detach(), {k: v.grad for k, v in lora.items()}

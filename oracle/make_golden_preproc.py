@@ -81,6 +81,26 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "g6_preprocess.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
+    # ---- g8: 128 mel bins (openai/whisper-large-v3's feature extractor = WhisperFeatureExtractor(feature_size=128); BASELINE config 5)
+    fe128 = WhisperFeatureExtractor(feature_size=128)
+    o8 = {"versions": out["versions"], "mel_filters_128": np.asarray(fe128.mel_filters, dtype=np.float64)}
+    assert np.abs(P.mel_filter_bank(n_mels=128) - o8["mel_filters_128"]).max() < 1e-15
+    for seed, n in WAVES[:3]:
+        w = wave_case(seed, n)
+        ref = fe128(w, sampling_rate=16000, return_tensors="pt").input_features.squeeze(0)
+        x = np.zeros(P.N_SAMPLES, dtype=np.float32); x[: min(n, P.N_SAMPLES)] = w[: P.N_SAMPLES]
+        ref64 = fe128._np_extract_fbank_features(x[None], "cpu")[0]
+        mine = P.log_mel(w, 128)
+        assert mine.shape == (128, 3000) and np.array_equal(mine, ref64), np.abs(mine - ref64).max()
+        d = np.abs(mine - ref.numpy()).max()
+        print(f"128 bins, wave seed {seed}: oracle == HF float64 path; vs HF torch float32 path {d:.2e}")
+        assert d < 5e-5
+        o8[f"wave{seed}_n"] = np.array([seed, n])
+        o8[f"wave{seed}_logmel64_sub"] = ref64[:, ::25].copy()
+        o8[f"wave{seed}_logmel_sub"] = ref.numpy()[:, ::25].copy()
+    path8 = os.path.join(ROOT, "tests", "golden", "g8_logmel128.npz")
+    np.savez_compressed(path8, **o8)
+    print("wrote", path8, os.path.getsize(path8), "bytes")
 
 
 if __name__ == "__main__":

@@ -60,8 +60,9 @@ def mel_filter_bank(n_freqs=N_FFT // 2 + 1, n_mels=N_MELS, fmin=0.0, fmax=8000.0
     return fb * enorm[None, :]
 
 
-def log_mel(wave):
-    """WhisperFeatureExtractor.__call__ on one mono 16 kHz waveform -> float32 [80, 3000]: truncate / zero-pad to 30 s,
+def log_mel(wave, n_mels=N_MELS):
+    """WhisperFeatureExtractor(feature_size=n_mels).__call__ on one mono 16 kHz waveform -> float32 [n_mels, 3000] (80 bins: Whisper
+    tiny..large-v2; 128 bins: large-v3, BASELINE config 5): truncate / zero-pad to 30 s,
     reflect-pad 200, 3001 Hann frames hop 160, rfft in float64 STORED AS complex64 (audio_utils.py:966), |.|^2 in float64,
     slaney mel, floor 1e-10, log10, cast float32, drop the last frame, clamp to max-8, (x+4)/4."""
     x = np.zeros(N_SAMPLES, dtype=np.float32)
@@ -73,7 +74,7 @@ def log_mel(wave):
     idx = np.arange(N_FFT)[None, :] + HOP * np.arange(nfr)[:, None]
     spec = np.fft.rfft(xp[idx] * win[None, :], axis=1).astype(np.complex64)
     power = np.abs(spec, dtype=np.float64) ** 2.0
-    mel = np.maximum(1e-10, mel_filter_bank().T @ power.T)
+    mel = np.maximum(1e-10, mel_filter_bank(n_mels=n_mels).T @ power.T)
     ls = np.log10(mel).astype(np.float32)[:, :-1]
     ls = np.maximum(ls, ls.max() - 8.0)
     return ((ls + 4.0) / 4.0).astype(np.float32)
@@ -87,8 +88,8 @@ def whole_tensor_layer_norm(f, eps=1e-5):
     return ((f - mu) / math.sqrt(var + eps)).astype(np.float32)
 
 
-def audio_features(wave, normalize=True):
-    f = log_mel(wave)
+def audio_features(wave, normalize=True, n_mels=N_MELS):
+    f = log_mel(wave, n_mels)
     return whole_tensor_layer_norm(f) if normalize else f
 
 

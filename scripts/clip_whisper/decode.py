@@ -53,7 +53,7 @@ def main():
         mp = os.path.join(root, a.test_manifest or cfg.get("test_manifest", "test.tsv"))
         lp = os.path.join(root, a.test_labels or cfg.get("test_labels", "test.wrd"))
         dl, _ = create_dataloaders(mp, lp, root, model.tokenizer, batch_size=a.batch_size, modality=a.modality, shuffle=False)
-        feats = (WhisperLogMel("cuda:0"), ClipFrames("cuda:0", image=model.cfg.clip.image))
+        feats = (WhisperLogMel("cuda:0", n_mels=model.cfg.whisper.n_mels), ClipFrames("cuda:0", image=model.cfg.clip.image))
 
         def batches_from_files():
             for b in dl:

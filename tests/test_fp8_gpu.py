@@ -58,7 +58,7 @@ def test_gemm_f8_matches_fake_quant_product(dev, M, N, K):
     out = ops.gemm_f8(Aq, As, Wq, Ws).float().cpu()
     assert rel_l2(out, ref) < 3e-3, rel_l2(out, ref)                          # bf16 rounding of the output only
     err = (out - ref.to(torch.bfloat16).float()).abs()
-    assert int((err > ref.abs() * 2.0 ** -7 + 1e-5).sum()) == 0
+    assert int((err > ref.abs() * 2.0 ** -7 + 4e-3).sum()) == 0             # one bf16 ulp + the fp32 summation-order slack on cancelling sums
     full = ops.gemm_f8(Aq, As, Wq, Ws, bias=bias, R=Rr, act=L.ACT_QUICK_GELU).float().cpu()
     z = ref + bias.float().cpu()
     ref2 = z * torch.sigmoid(1.702 * z) + Rr.float().cpu()
@@ -92,3 +92,51 @@ def test_gemm_f8_identity_asymmetric(dev):
     Bq, Bs = ops.mx_quantize(B, 1)
     out = ops.gemm_f8(Aq, As, Bq, Bs).float()
     assert torch.equal(out, 4.0 * B.float().t())
+
+
+def test_model_fp8_train_step_vs_fake_quant_oracle(dev, golden_dir):
+    """precision="fp8" end to end on the golden tiny model: encoders (fp8 projections) and one LoRA train step (fp8 frozen projections in the
+    forward, bf16 backward) against the oracle run with the same MX fake-quantisation; bars in tests/bars.py.  Also: the step's distance from
+    the unquantised oracle (what fp8 costs), and an fp8 trainer step that actually moves the LoRA parameters."""
+    import bars as Bar
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    from avllm.trainer import ClipWhisperTrainer
+    from oracle import avsr_oracle as O
+    from oracle import weights as Wt
+    g = np.load(f"{golden_dir}/g2_tiny_e2e.npz")
+    oc = Wt.tiny()
+    W = Wt.all_weights(oc, int(g["seed"]), lora_b_std=0.05)
+    audio, video, labels, _ = Wt.synthetic_batch(oc, 2, int(g["frames"]), seed=int(g["batch_seed"]))
+    prompt = torch.from_numpy(g["prompt"])
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    m = ClipWhisperModel(device="cuda:0", lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=512, config=cfg, weights=W,
+                         precision="fp8").train()
+    assert m.fp8 and m.llm_engine.desc.fp8 == 1 and m.whisper_engine.desc.fp8 == 1 and m.clip_engine.desc.fp8 == 1
+    fr = video.reshape(-1, 3, oc.clip.image, oc.clip.image)
+    with torch.no_grad(), O.fp8_mode():
+        ref_w = O.whisper_encoder(W["whisper"], oc.whisper, audio)
+        ref_c = O.clip_vision_cls(W["clip"], oc.clip, fr)
+    assert rel_l2(m.whisper_engine.forward(audio.to(dev)).float().cpu(), ref_w) < Bar.FP8_ENC_REL_L2
+    assert rel_l2(m.clip_engine.forward(fr.to(dev)).float().cpu(), ref_c) < Bar.FP8_ENC_REL_L2
+    out = m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    m.lora_param.grad = None
+    out["loss"].backward()
+    with O.fp8_mode():
+        ol, ologits, og = O.train_step_grads(W, oc, audio, video, prompt, labels)
+    logits = out["logits"].float().cpu()
+    assert rel_l2(logits, ologits) < Bar.FP8_LOGITS_REL_L2, rel_l2(logits, ologits)
+    assert abs(float(out["loss"].detach()) - float(ol)) < Bar.FP8_LOSS_ABS
+    gv = {k: v.cpu() for k, v in m.llm_engine.lora_views(m.lora_param.grad).items()}
+    keys = sorted(gv)
+    whole = rel_l2(torch.cat([gv[k].flatten() for k in keys]), torch.cat([og[k].flatten() for k in keys]))
+    assert whole < Bar.FP8_GRAD_REL_L2, whole
+    # what the quantisation costs against the unquantised reference arithmetic (the reference-generated golden logits)
+    gold = torch.from_numpy(g["train_logits"])
+    cost = rel_l2(logits, gold)
+    assert 1e-3 < cost < Bar.FP8_VS_UNQUANTISED_REL_L2, cost
+    # and the trainer steps in fp8 (graph-replayed like any other precision)
+    tr = ClipWhisperTrainer(m, learning_rate=1e-3, total_steps=10, max_epochs=1)
+    p0 = m.llm_engine.lora_p.clone()
+    losses = [float(tr.train_step(audio.to(dev), video.to(dev), labels.to(dev), prompt.to(dev))) for _ in range(3)]
+    assert all(np.isfinite(losses)) and not torch.equal(p0, m.llm_engine.lora_p) and losses[-1] < losses[0] + 0.05

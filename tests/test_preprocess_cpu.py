@@ -48,3 +48,17 @@ def test_clip_frames_bit_exact(g6, seed, h, w):
 def test_resize_shape_rule():
     assert P.clip_resize_shape(96, 128) == (224, 298) and P.clip_resize_shape(300, 260) == (258, 224)
     assert P.clip_resize_shape(224, 224) == (224, 224) and P.clip_resize_shape(225, 223) == (226, 224)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_log_mel_128_bins(golden_dir, seed):
+    """128 mel bins (openai/whisper-large-v3's extractor, BASELINE config 5) against tests/golden/g8_logmel128.npz, generated from
+    transformers' WhisperFeatureExtractor(feature_size=128): exact on HF's float64 definition, inside HF's own spread on its torch path."""
+    g8 = np.load(f"{golden_dir}/g8_logmel128.npz")
+    _, n = (int(v) for v in g8[f"wave{seed}_n"])
+    from oracle.make_golden_preproc import wave_case
+    f = P.log_mel(wave_case(seed, n), 128)
+    assert f.shape == (128, 3000) and f.dtype == np.float32
+    assert np.array_equal(f[:, ::25], g8[f"wave{seed}_logmel64_sub"])
+    assert np.abs(f[:, ::25] - g8[f"wave{seed}_logmel_sub"]).max() < 5e-5
+    assert np.abs(P.mel_filter_bank(n_mels=128) - g8["mel_filters_128"]).max() < 1e-15

@@ -100,3 +100,22 @@ def test_model_from_raw_inputs_equals_model_from_oracle_features(dev):
     o1 = m(audio=audio, video=video, prompt=None, labels=labels.to(dev))
     o2 = m(audio=ref_a.to(dev), video=ref_v.to(dev), prompt=None, labels=labels.to(dev))
     assert (o1["logits"] - o2["logits"]).abs().max() < 1e-3 and abs(float(o1["loss"].detach()) - float(o2["loss"].detach())) < 1e-4
+
+
+def test_log_mel_128_bins_vs_oracle_and_fixture(dev, golden_dir):
+    """The device log-mel with 128 bins (Whisper-large-v3, BASELINE config 5): kernel vs the numpy oracle and the HF-generated fixture g8."""
+    from avllm.preprocess import WhisperLogMel
+    from oracle.make_golden_preproc import wave_case
+    g8 = np.load(f"{golden_dir}/g8_logmel128.npz")
+    lm = WhisperLogMel(dev, normalize=False, n_mels=128)
+    cases = [tuple(int(v) for v in g8[f"wave{s}_n"]) for s in (1, 2, 3)]
+    waves = [wave_case(s, n) for s, n in cases]
+    raw = lm(waves).cpu().numpy()
+    assert raw.shape == (3, 128, 3000)
+    for i, (s, n) in enumerate(cases):
+        assert np.abs(raw[i] - P.log_mel(waves[i], 128)).max() < 2e-6
+        assert np.abs(raw[i][:, ::25] - g8[f"wave{s}_logmel_sub"]).max() < 5e-5
+    normed = WhisperLogMel(dev, normalize=True, n_mels=128)(waves[:1]).cpu().numpy()[0]
+    assert np.abs(normed - P.audio_features(waves[0], n_mels=128)).max() < 2e-5
+    with pytest.raises(ValueError):
+        WhisperLogMel(dev, n_mels=100)
