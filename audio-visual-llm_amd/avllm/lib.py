@@ -107,6 +107,7 @@ _SIGS = {
     "avllm_argmax_rows": ([vp, i64, i64, i32, vp, i32, vp], i32),
     "avllm_embedding": ([vp, vp, vp, i64, i32, i32, vp], i32),
     "avllm_cast": ([vp, i32, vp, i32, i64, vp], i32),
+    "avllm_act_residual": ([vp, vp, vp, i64, i32, i32, vp], i32),
     "avllm_dropout": ([vp, vp, i64, i32, C.c_uint32, f32, i32, vp], i32),
     "avllm_whisper_im2col1": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "avllm_whisper_im2col2": ([vp, vp, i32, i32, i32, i32, vp], i32),

@@ -173,6 +173,14 @@ def cast(x, dtype):
     return out
 
 
+def act_residual(x, act, r=None):
+    """act(x) + r elementwise (avllm_act_residual)."""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().avllm_act_residual(L.ptr(x), L.ptr(r.contiguous()) if r is not None else None, L.ptr(y), x.numel(), act, L.dt_of(x), L.stream_ptr()))
+    return y
+
+
 def fuse_pool(a, v, prompt_emb, L_, S_out, fusion_scale, D, B):
     """See avllm_fuse_pool in include/avllm.h.  a [B,Ta,D] | None, v [B,Tv,D] | None, prompt_emb [B,P,D] | None."""
     ref = a if a is not None else v

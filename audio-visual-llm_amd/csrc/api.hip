@@ -65,6 +65,7 @@ int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, fl
                      const avllm_step_state* state, void* stream) {
     return av_adamw_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, sumsq, max_norm, prescale, guard, skipped, state, ST);
 }
+int avllm_act_residual(const void* x, const void* r, void* y, int64_t n, int32_t act, int32_t dtype, void* stream) { return av_act_residual(x, r, y, n, act, dtype, ST); }
 int avllm_step_advance(avllm_step_state* state, const avllm_schedule* sched, void* stream) { return av_step_advance(state, sched, ST); }
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad, int64_t ld_at,
                     void* B_pad, void* BT_pad, int32_t dtype, void* stream) { return av_lora_pack(A, Bm, r, din, dout, A_pad, AT_pad, ld_at, B_pad, BT_pad, dtype, ST); }

@@ -53,4 +53,5 @@ int av_lora_dx_masked(const void* const* T, const long* ldt, const void* const* 
                       const void* R, long ldr, void* out, long ldo, int M, int N, float p, const uint32_t* seed_dev, int dtype, hipStream_t st);
 int av_mx_quantize(const void* x, long ldx, int R, int K, void* q, long ldq, void* scales, int layout, int dtype, hipStream_t st);
 int av_gemm_f8(const avllm_gemm_f8_desc* d, hipStream_t st);
+int av_act_residual(const void* x, const void* r, void* y, long n, int act, int dtype, hipStream_t st);
 int av_step_advance(avllm_step_state* state, const avllm_schedule* sched, hipStream_t st);

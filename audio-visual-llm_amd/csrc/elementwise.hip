@@ -109,6 +109,20 @@ __global__ void swiglu_bwd_kernel(const T* __restrict__ dh, const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- y = act(x) + r  (DeepModalityConnector: Linear -> LayerNorm -> GELU [+ residual],
+// src/clip_whisper/models/modality_connector.py:91-108: the norm sits between the projection and the activation, so the GEMM epilogue cannot carry it)
+template <typename T>
+__global__ void act_residual_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y, long n4, int act) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+        load_f<4>(x + idx * 4, v);
+        if (r) load_f<4>(r + idx * 4, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], act) + rr[j];
+        store_f<4>(y + idx * 4, v);
+    }
+}
+
 // ---------------------------------------------------------------- dropout (counter-based mask, common.h av_keep)
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int d, uint32_t seed_off, float p, const uint32_t* seed_dev) {
@@ -392,6 +406,14 @@ int av_swiglu_bwd(const void* dh, const void* gu, void* dgu, long M, int F, int 
     AV_CHECK_ARG(dh && gu && dgu && M > 0 && F % 4 == 0, "swiglu_bwd: bad args");
     if (dtype == AV_F32) hipLaunchKernelGGL((swiglu_bwd_kernel<float>), dim3(grid_for(M * (F / 4))), dim3(256), 0, st, (const float*)dh, (const float*)gu, (float*)dgu, M, F);
     else hipLaunchKernelGGL((swiglu_bwd_kernel<bf16>), dim3(grid_for(M * (F / 4))), dim3(256), 0, st, (const bf16*)dh, (const bf16*)gu, (bf16*)dgu, M, F);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_act_residual(const void* x, const void* r, void* y, long n, int act, int dtype, hipStream_t st) {
+    AV_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "act_residual: bad args (n=%ld must be a multiple of 4)", n);
+    if (dtype == AV_F32) hipLaunchKernelGGL((act_residual_kernel<float>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)x, (const float*)r, (float*)y, n / 4, act);
+    else hipLaunchKernelGGL((act_residual_kernel<bf16>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const bf16*)x, (const bf16*)r, (bf16*)y, n / 4, act);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -160,6 +160,8 @@ int avllm_argmax_rows(const void* logits, int64_t ld, int64_t rows, int32_t V, i
 /* out[i,:] = table[ids[i],:] ; llm.get_input_embeddings() (clip_whisper_model.py:464-487) */
 int avllm_embedding(const void* table, const int64_t* ids, void* out, int64_t n, int32_t d, int32_t dtype, void* stream);
 int avllm_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
+/* y = act(x) + r (r may be NULL; y may alias x): the activation / residual steps of DeepModalityConnector (modality_connector.py:91-108) */
+int avllm_act_residual(const void* x, const void* r, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
 /* nn.Dropout(p) of peft's lora.Linear (lora_dropout, clip_whisper_model.py:973-982): y = x * keep / (1-p) with the
  * counter-based mask keep(seed, row*d+col, p) (csrc/common.h av_keep); the same (seed,p) regenerates the same mask. */
 int avllm_dropout(const void* x, void* y, int64_t rows, int32_t d, uint32_t seed, float p, int32_t dtype, void* stream);

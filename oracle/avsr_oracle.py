@@ -148,8 +148,17 @@ def clip_vision_cls(sd, c, frames):
 
 # --------------------------------------------------------------------------- reference glue
 def connector(sd, x):
-    """SimpleModalityConnector.forward, modality_connector.py:16-20,43-44."""
-    return x @ sd["linear.weight"].T + sd["linear.bias"]
+    """SimpleModalityConnector.forward, modality_connector.py:16-20,43-44; DeepModalityConnector._forward_impl :91-108 when the state dict
+    carries its keys (input_proj / hidden_layers.N.{0,1} / output_proj / *_norm; nn.GELU() = erf form, LayerNorm eps 1e-5)."""
+    if "linear.weight" in sd:
+        return x @ sd["linear.weight"].T + sd["linear.bias"]
+    h = gelu_erf(layer_norm(x @ sd["input_proj.weight"].T + sd["input_proj.bias"], sd["input_norm.weight"], sd["input_norm.bias"]))
+    i = 0
+    while f"hidden_layers.{i}.0.weight" in sd:
+        p = f"hidden_layers.{i}."
+        h = gelu_erf(layer_norm(h @ sd[p + "0.weight"].T + sd[p + "0.bias"], sd[p + "1.weight"], sd[p + "1.bias"])) + h
+        i += 1
+    return layer_norm(h @ sd["output_proj.weight"].T + sd["output_proj.bias"], sd["output_norm.weight"], sd["output_norm.bias"])
 
 
 def pad_or_truncate(x, target_len):

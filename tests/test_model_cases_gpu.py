@@ -194,3 +194,22 @@ def test_same_seed_same_model(dev):
             outs.append(m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))["logits"].clone())
     assert torch.equal(outs[0], outs[1])
     assert not torch.equal(outs[0], outs[2])
+
+
+def test_deep_connector_matches_reference_fixture(dev, golden_dir):
+    """`connector_type="deep"` (and any unknown name: the reference's factory falls back to it, modality_connector.py:394-396) against the
+    output of the REFERENCE's DeepModalityConnector on the same parameters (tests/golden/g9_deep_connector.npz); conv/attention/adaptive
+    are refused by name."""
+    import numpy as np
+    from avllm.connector import DeepModalityConnector, create_modality_connector
+    g = np.load(f"{golden_dir}/g9_deep_connector.npz")
+    for tag, name in (("a", "deep"), ("b", "perceiver")):
+        layers = int(g[tag + ".layers"])
+        for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 6e-2)):
+            c = create_modality_connector(name, 48, 96, device=dev, dtype=dtype, num_layers=layers)
+            assert isinstance(c, DeepModalityConnector)
+            c.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")})
+            y = c(torch.from_numpy(g[tag + ".x"]).to(dev)).float().cpu()
+            assert y.shape == (2, 9, 96) and (y - torch.from_numpy(g[tag + ".y"])).abs().max() < tol
+    with pytest.raises(NotImplementedError):
+        create_modality_connector("conv", 48, 96, device=dev)

@@ -158,3 +158,13 @@ def test_mxfp8_restatement_matches_the_mx_rule():
                 if abs(cands[0] - t) == abs(cands[1] - t):                      # tie: even mantissa
                     best = cands[0] if (np.frexp(cands[0])[0] * 16) % 2 == 0 else cands[1]
                 assert abs(abs(d) - best * 2.0 ** ee) <= 1e-12 * max(1.0, abs(d)), (r, b, v, d, best * 2.0 ** ee)
+
+
+def test_deep_connector_golden(golden_dir):
+    """oracle connector() for the reference's DeepModalityConnector against tests/golden/g9_deep_connector.npz (oracle/make_golden_connector.py
+    ran the reference's own class, 2- and 4-layer, the latter requested through the factory's unknown-name fallback)."""
+    g = np.load(f"{golden_dir}/g9_deep_connector.npz")
+    for tag in ("a", "b"):
+        sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
+        y = O.connector(sd, torch.from_numpy(g[tag + ".x"]))
+        assert (y - torch.from_numpy(g[tag + ".y"])).abs().max() < 2e-6
