@@ -218,6 +218,34 @@ def _cfg_from_hf_dir(path, kind):
                     c.get("rms_norm_eps", 1e-5), rope, 0 if kvh == c["num_attention_heads"] else kvh)
 
 
+def weights_from_reference_state_dict(sd):
+    """`model_state_dict` of a checkpoint written by the REFERENCE trainer (trainer/clip_whisper_trainer.py:752-760: the full
+    ClipWhisperModel.state_dict(), frozen encoders and LLM included, LoRA under peft's key names) -> the `weights=` dict of ClipWhisperModel:
+    {"whisper", "clip", "llama"} in HuggingFace naming, {"lora"} as `layers.N.<module>.lora_A|B`, and the two connector state dicts.
+    Sub-dicts that the checkpoint does not carry are simply absent (decode.py-style checkpoints hold the connectors only)."""
+    W = {"whisper": {}, "clip": {}, "llama": {}, "lora": {}, "audio_connector": {}, "video_connector": {}}
+    for k, v in sd.items():
+        if k.startswith("whisper."):
+            W["whisper"][k[len("whisper."):]] = v
+        elif k.startswith("clip."):
+            W["clip"][k[len("clip."):]] = v
+        elif k.startswith("audio_connector."):
+            W["audio_connector"][k[len("audio_connector."):]] = v
+        elif k.startswith("video_connector."):
+            W["video_connector"][k[len("video_connector."):]] = v
+        elif k.startswith("llm."):
+            n = k[len("llm."):]
+            if n.startswith("base_model.model."):                      # peft: PeftModel.base_model (LoraModel) .model
+                n = n[len("base_model.model."):]
+            if ".lora_A." in n or ".lora_B." in n:                        # model.layers.N.self_attn.q_proj.lora_A.default.weight
+                parts = n.split(".")
+                i, mod = parts[parts.index("layers") + 1], parts[parts.index("self_attn") + 1]
+                W["lora"][f"layers.{i}.{mod}.{'lora_A' if '.lora_A.' in n else 'lora_B'}"] = v
+            else:
+                W["llama"][n.replace(".base_layer.", ".")] = v            # peft keeps the frozen nn.Linear as `base_layer`
+    return {k: v for k, v in W.items() if v}
+
+
 def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lora_r, lora_alpha, use_lora, p_llm, p_whisper,
                  p_clip, device, dtype, synthetic_weights=False):
     """-> (ModelCfg, weights).  A component's tensors come from `weights[kind]`, a `_provided_*` module, or a local HF directory with

@@ -296,27 +296,76 @@ class ClipWhisperTrainer:
         self.model.train()
         return tot / max(1, cnt)
 
+    def _lora_keys(self):
+        """peft-named LoRA keys in the order torch's optimizer indexes them (state-dict order: per layer q,k,v,o; A then B) == the order of
+        the flat LoRA buffer."""
+        eng = self.model.llm_engine
+        from .engine import LORA_TARGETS
+        return [f"llm.base_model.model.model.layers.{i}.self_attn.{nm}.{ab}.default.weight" for i in range(eng.cfg.layers) for nm in LORA_TARGETS
+                for ab in ("lora_A", "lora_B")]
+
     def _save_checkpoint(self, epoch, name):
-        """Same keys as trainer:752-760; model_state_dict holds the tensors this build owns (connectors + LoRA)."""
+        """Same top-level keys as trainer:752-760.  model_state_dict holds the tensors this build owns (connectors + LoRA under peft's key
+        names: decode.py:236-260 extracts the connectors by substring); the frozen encoders / LLM the reference also dumps into every
+        checkpoint (13.5 GB for a 7B LLM) are not repeated -- they are the checkpoints the model was built from.  optimizer_state_dict /
+        scheduler_state_dict follow torch.optim.AdamW / CosineAnnealingLR's own layout for the LoRA parameters, in optimizer index order."""
         if is_dist() and torch.distributed.get_rank() != 0:
             return
         os.makedirs(self.output_dir, exist_ok=True)
         path = os.path.join(self.output_dir, name)
+        eng = self.model.llm_engine
+        state, n = {}, 0
+        mv, vv = eng.lora_views(self.m), eng.lora_views(self.v)
+        for i, key in enumerate(self._lora_keys()):
+            _, _, _, _, _, li, _, mod, ab, _, _ = key.split(".")
+            short = f"layers.{li}.{mod}.{ab}"
+            state[i] = {"step": torch.tensor(float(self.global_step)), "exp_avg": mv[short].detach().cpu().clone(), "exp_avg_sq": vv[short].detach().cpu().clone()}
+            n += 1
+        group = {"lr": self.lr_at(self.global_step), "betas": (0.9, 0.95), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None, "initial_lr": self.learning_rate,
+                 "params": list(range(n))}
         torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
-                    "optimizer_state_dict": {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.global_step},
-                    "scheduler_state_dict": {"step": self.global_step, "total_steps": self.total_steps},
+                    "optimizer_state_dict": {"state": state, "param_groups": [group]},
+                    "scheduler_state_dict": {"T_max": self.total_steps, "eta_min": 0.0, "base_lrs": [self.learning_rate], "last_epoch": self.global_step,
+                                             "_step_count": self.global_step + 1, "_last_lr": [self.lr_at(self.global_step)]},
                     "train_losses": self.train_losses, "val_losses": self.val_losses, "best_val_loss": self.best_val_loss}, path)
         json.dump({"epoch": epoch, "global_step": self.global_step, "best_val_loss": self.best_val_loss},
                   open(path.replace(".pt", "_meta.json"), "w"))
 
     def load_checkpoint(self, path):
+        """trainer:796-854.  Reads a checkpoint of this build AND one written by the reference trainer: connectors + LoRA from
+        model_state_dict, Adam moments from torch's optimizer state (the only parameters with state are the ones that ever received a
+        gradient -- the LoRA tensors, SURVEY.md fact 4 -- in state-dict order), the step count from the scheduler's last_epoch."""
         ck = torch.load(path, map_location="cpu", weights_only=True)
         self.model.load_state_dict(ck["model_state_dict"])
+        eng = self.model.llm_engine
         o = ck.get("optimizer_state_dict") or {}
-        if "m" in o:
-            self.m.copy_(o["m"]); self.v.copy_(o["v"]); self.global_step = int(o.get("step", 0))
-            self.state.view(torch.int32)[0] = self.global_step          # the device-side step count drives lr / bias corrections / seeds
-        self.train_losses, self.val_losses = ck.get("train_losses", []), ck.get("val_losses", [])
+        step = None
+        if "m" in o:                                             # round-1 layout of this build
+            self.m.copy_(o["m"]); self.v.copy_(o["v"]); step = int(o.get("step", 0))
+        elif "state" in o:
+            ids = sorted(int(k) for k, st in o["state"].items() if isinstance(st, dict) and "exp_avg" in st)
+            keys = self._lora_keys()
+            if len(ids) != len(keys):
+                raise ValueError(f"optimizer state has {len(ids)} tensors with moments, the model has {len(keys)} LoRA tensors")
+            mv, vv = eng.lora_views(self.m), eng.lora_views(self.v)
+            for idx, key in zip(ids, keys):
+                st = o["state"][idx] if idx in o["state"] else o["state"][str(idx)]
+                _, _, _, _, _, li, _, mod, ab, _, _ = key.split(".")
+                short = f"layers.{li}.{mod}.{ab}"
+                if tuple(st["exp_avg"].shape) != tuple(mv[short].shape):
+                    raise ValueError(f"optimizer state {idx} has shape {tuple(st['exp_avg'].shape)}, {key} is {tuple(mv[short].shape)}")
+                mv[short].copy_(st["exp_avg"]); vv[short].copy_(st["exp_avg_sq"])
+                step = int(float(st["step"]))
+        sched = ck.get("scheduler_state_dict") or {}
+        if "last_epoch" in sched:
+            step = int(sched["last_epoch"])
+        elif "step" in sched:
+            step = int(sched["step"])
+        if step is not None:
+            self.global_step = step
+            self.state.view(torch.int32)[0] = step                 # the device-side step count drives lr / bias corrections / seeds
+        self.train_losses, self.val_losses = list(ck.get("train_losses", [])), list(ck.get("val_losses", []))
         self.best_val_loss = ck.get("best_val_loss", float("inf"))
         return ck.get("epoch", 0)
 

@@ -126,3 +126,29 @@ def test_unresolvable_model_paths_raise_instead_of_random_weights(tmp_path):
     with pytest.raises(Exception) as ei:                            # a BROKEN tokenizer must surface, not turn into the byte stand-in
         load_tokenizer(str(tmp_path), 32000, synthetic=True)
     assert not isinstance(ei.value, FileNotFoundError) or "tokenizer files" not in str(ei.value)
+
+
+def test_reference_trainer_checkpoint_maps_to_build_weights(golden_dir):
+    """tests/golden/n1_reference_model_best.pt is the file the REFERENCE trainer's own _save_checkpoint wrote (oracle/make_golden_checkpoint.py).
+    The safe loader accepts it; its full model_state_dict maps onto this build's `weights=` layout: frozen tensors equal the seeded weights
+    the reference model was built from, LoRA tensors (two optimizer steps old) differ from their initial values, connectors untouched
+    (no gradient reaches them)."""
+    import numpy as np
+    from avllm.arch import weights_from_reference_state_dict
+    from oracle import weights as Wt
+    from oracle.make_golden_checkpoint import micro_cfg
+    ck = torch.load(f"{golden_dir}/n1_reference_model_best.pt", map_location="cpu", weights_only=True)
+    assert {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "train_losses", "val_losses", "best_val_loss"} <= set(ck)
+    W = weights_from_reference_state_dict(ck["model_state_dict"])
+    cfg = micro_cfg()
+    W0 = Wt.all_weights(cfg, int(np.load(f"{golden_dir}/n1_expected.npz")["weights_seed"]), lora_b_std=0.05)
+    assert set(W) == {"whisper", "clip", "llama", "lora", "audio_connector", "video_connector"}
+    for part in ("whisper", "clip", "llama", "audio_connector", "video_connector"):
+        for k, v in W0[part].items():
+            kk = k if k in W[part] else ("vision_model." + k if "vision_model." + k in W[part] else k)
+            assert kk in W[part], (part, k, list(W[part])[:4])
+            assert torch.equal(W[part][kk], v), (part, k)
+    assert set(W["lora"]) == set(W0["lora"])
+    assert any(not torch.equal(W["lora"][k], W0["lora"][k]) for k in W0["lora"])
+    st = ck["optimizer_state_dict"]["state"]
+    assert len([i for i in st if "exp_avg" in st[i]]) == len(W["lora"]) and ck["scheduler_state_dict"]["last_epoch"] == 2

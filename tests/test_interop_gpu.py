@@ -67,3 +67,65 @@ def test_hf_checkpoints_load_and_match_oracle(dev, tmp_path, how):
     out = m.train()(audio=audio.to(dev), video=video.to(dev), prompt=None, labels=labels.to(dev))
     assert (out["logits"].float().cpu() - ref["logits"]).abs().max() < 1e-3
     assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-4
+
+
+def test_reference_trainer_checkpoint_resumes_exactly(dev, golden_dir, tmp_path):
+    """SURVEY.md §8f N1, both directions.
+    (1) reference -> build: the checkpoint written by the reference trainer (tests/golden/n1_reference_model_best.pt) restores model,
+    Adam moments and schedule position; the next forward equals the reference's, and the next optimizer step lands on the reference's
+    parameters (tests/golden/n1_expected.npz holds what the reference computed from that state).
+    (2) build -> reference: a checkpoint of this build passes the reference's own consumers' rules: decode.py:236-260 pulls the connectors by
+    substring and load_state_dict()s them into fresh connector modules; the optimizer / scheduler dicts have torch's own layout."""
+    import numpy as np
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg, weights_from_reference_state_dict
+    from avllm.model import ClipWhisperModel
+    from avllm.tokenizer import ByteTokenizer
+    from avllm.trainer import ClipWhisperTrainer
+    from oracle.make_golden_checkpoint import micro_cfg
+    exp = np.load(f"{golden_dir}/n1_expected.npz")
+    path = f"{golden_dir}/n1_reference_model_best.pt"
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    oc = micro_cfg()
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    m = ClipWhisperModel(device=dev, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=512, config=cfg,
+                         weights=weights_from_reference_state_dict(ck["model_state_dict"]), precision="fp32",
+                         _provided_tokenizer=ByteTokenizer(oc.llama.vocab)).train()
+    tr = ClipWhisperTrainer(m, learning_rate=float(exp["lr"]), weight_decay=float(exp["wd"]), grad_clip=float(exp["clip"]),
+                            total_steps=int(exp["total_steps"]), max_epochs=1, output_dir=str(tmp_path), use_graph=False)
+    assert tr.load_checkpoint(path) == ck["epoch"] and tr.global_step == 2 and tr.train_losses == pytest.approx(list(exp["losses_12"]))
+    st = ck["optimizer_state_dict"]["state"]
+    ids = sorted(i for i in st if "exp_avg" in st[i])
+    mv = m.llm_engine.lora_views(tr.m)
+    assert torch.equal(mv["layers.0.q_proj.lora_A"].cpu(), st[ids[0]]["exp_avg"]) and torch.equal(mv["layers.0.o_proj.lora_B"].cpu(), st[ids[-1]]["exp_avg"])
+    audio, video, labels, prompt = Wt.synthetic_batch(oc, 2, 3, seed=int(exp["seeds"][2]))
+    out = m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    assert abs(float(out["loss"].detach()) - float(exp["train_loss_3"])) < 1e-4
+    assert (out["logits"].float().cpu()[:, ::8] - torch.from_numpy(exp["train_logits_3_sub"])).abs().max() < 1e-3
+    tr.train_step(audio.to(dev), video.to(dev), labels.to(dev), prompt.to(dev))
+    sd = m.state_dict()
+    num = den = 0.0
+    for k in exp.files:
+        if k.startswith("after3."):
+            mine, ref, before = sd[k[7:]].cpu(), torch.from_numpy(exp[k]), ck["model_state_dict"][k[7:]]
+            num += float(((mine - before) - (ref - before)).pow(2).sum()); den += float((ref - before).pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5            # the third step's UPDATE, relative L2 (Adam amplifies rounding near zero)
+    # ---- (2) this build's checkpoint through the reference's consumers' rules
+    tr._save_checkpoint(0, "model_final.pt")
+    mine = torch.load(tmp_path / "model_final.pt", map_location="cpu", weights_only=True)
+    assert set(ck) <= set(mine)
+    state_dict = mine["model_state_dict"]
+    audio_connector_dict = {k.replace("audio_connector.", ""): v for k, v in state_dict.items() if "audio_connector" in k}      # decode.py:237
+    video_connector_dict = {k.replace("video_connector.", ""): v for k, v in state_dict.items() if "video_connector" in k}      # decode.py:238
+    for d_, dim in ((audio_connector_dict, oc.whisper.d_model), (video_connector_dict, oc.clip.hidden)):
+        fresh = torch.nn.Module()
+        fresh.linear = torch.nn.Linear(dim, oc.llama.hidden)                  # the module tree of the reference's ModalityConnector
+        fresh.load_state_dict(d_)                                              # strict, as decode.py:250,258
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros_like(v)) for k, v in state_dict.items() if "lora_" in k], lr=1e-3, betas=(0.9, 0.95))
+    opt.load_state_dict(mine["optimizer_state_dict"])                          # torch's own loader accepts the layout
+    assert float(opt.state_dict()["state"][0]["step"]) == 3.0
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=int(exp["total_steps"]))
+    sched.load_state_dict(mine["scheduler_state_dict"])
+    assert sched.last_epoch == 3
+    tr2 = ClipWhisperTrainer(m, learning_rate=float(exp["lr"]), total_steps=int(exp["total_steps"]), max_epochs=1, use_graph=False)
+    tr2.load_checkpoint(tmp_path / "model_final.pt")
+    assert tr2.global_step == 3 and torch.equal(tr2.m, tr.m) and torch.equal(tr2.v, tr.v)
