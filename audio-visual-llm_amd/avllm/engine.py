@@ -157,7 +157,9 @@ class ClipEngine:
         if frames.shape[-1] != self.cfg.image or frames.shape[-2] != self.cfg.image:
             raise ValueError(f"Input image size ({frames.shape[-2]}*{frames.shape[-1]}) doesn't match model ({self.cfg.image}*{self.cfg.image}).")
         lib = L.load()
-        frames = frames.to(device=self.device, dtype=torch.float32).contiguous()
+        # fp32 pixel_values as the reference's CLIPProcessor hands them over, or bf16 (device-side preprocessing, avllm.preprocess.ClipFrames)
+        frames = frames.to(device=self.device, dtype=torch.bfloat16 if frames.dtype == torch.bfloat16 else torch.float32).contiguous()
+        self.desc.frames_bf16 = int(frames.dtype == torch.bfloat16)
         N = frames.shape[0]
         out = torch.empty(N, self.cfg.hidden, device=self.device, dtype=self.dtype)
         step = self.chunk if self.chunk and self.chunk < N else N
@@ -347,6 +349,32 @@ class LlamaEngine:
                                                 hi, layer_lo, cb, None, L.stream_ptr()))
 
     # ------------------------------------------------------------------ inference
+    def adapters_disabled(self):
+        """Context manager: the LLM without its LoRA adapters, as scripts/clip_whisper/decode.py of the reference runs it (it rebuilds the
+        model with use_lora=False and loads the connector weights only, decode.py:186-197,236-260)."""
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.saved = [[(ly.lora[j].A_pad, ly.lora[j].B_pad) for j in range(4)] for ly in eng.layers]
+                for ly in eng.layers:
+                    for j in range(4):
+                        ly.lora[j].A_pad = None
+                        ly.lora[j].B_pad = None
+
+            def __exit__(self_, *a):
+                for ly, sv in zip(eng.layers, self_.saved):
+                    for j in range(4):
+                        ly.lora[j].A_pad, ly.lora[j].B_pad = sv[j]
+        return _Ctx()
+
+    def frozen_weight_bytes(self):
+        """Bytes of frozen weights ONE decode token step streams from HBM: every projection of every layer + lm_head (the embedding
+        table contributes B rows, the norms 2 vectors per layer: both negligible and left out)."""
+        d, f = self.cfg.hidden, self.cfg.ffn
+        per_layer = (d + 2 * self.dkv) * d + d * d + 2 * f * d + d * f
+        return (self.cfg.layers * per_layer + self.cfg.vocab * d) * (4 if self.dtype == torch.float32 else 2)
+
     def alloc_cache(self, B, Tmax):
         shape = (self.cfg.layers, B, Tmax, self.dkv)
         return torch.empty(shape, dtype=self.dtype, device=self.device), torch.empty(shape, dtype=self.dtype, device=self.device)

@@ -43,7 +43,7 @@ class Whisper(C.Structure):
 class Clip(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "image", "patch", "tokens")] + \
                [("eps", f32)] + [(n, vp) for n in ("patch_w", "class_emb", "pos", "pre_ln_w", "pre_ln_b")] + \
-               [("layer", C.POINTER(EncLayer)), ("fp8", i32)]
+               [("layer", C.POINTER(EncLayer)), ("fp8", i32), ("frames_bf16", i32)]
 
 
 class LoraMod(C.Structure):

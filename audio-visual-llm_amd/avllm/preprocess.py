@@ -35,8 +35,9 @@ class WhisperLogMel:
             out[i, : w.numel()] = w.to(self.device, non_blocking=True)
         return out
 
-    def __call__(self, wave):
-        """wave: [B, n] float32 (rows zero-padded) or a list of 1-D waveforms -> [B, n_mels, 3000] float32 on the device."""
+    def __call__(self, wave, out=None):
+        """wave: [B, n] float32 (rows zero-padded) or a list of 1-D waveforms -> [B, n_mels, 3000] float32 on the device
+        (written into `out` when given: a feeder filling a captured step's input buffer)."""
         if isinstance(wave, (list, tuple)):
             wave = self.pad_batch(wave)
         if wave.dim() == 1:
@@ -49,7 +50,10 @@ class WhisperLogMel:
         need = lib.avllm_logmel_workspace_bytes(B, self.n_mels)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out = torch.empty(B, self.n_mels, N_FRAMES, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(B, self.n_mels, N_FRAMES, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (B, self.n_mels, N_FRAMES) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != wave.device:
+            raise ValueError(f"out should be a contiguous float32 [{B}, {self.n_mels}, {N_FRAMES}] tensor on {wave.device}, but got {out.dtype} {tuple(out.shape)}")
         L.check(lib.avllm_logmel(L.ptr(self.table), L.ptr(wave), B, n, wave.stride(0), int(self.normalize), self.n_mels, L.ptr(out),
                                  L.ptr(self._ws), self._ws.numel(), L.stream_ptr()))
         return out
@@ -71,8 +75,8 @@ class ClipFrames:
             self._plans[key] = buf
         return self._plans[key]
 
-    def __call__(self, frames):
-        """frames: uint8 [N, H, W, 3] RGB (any H, W) -> pixel_values [N, 3, image, image]."""
+    def __call__(self, frames, out=None):
+        """frames: uint8 [N, H, W, 3] RGB (any H, W) -> pixel_values [N, 3, image, image] (written into `out` when given)."""
         frames = torch.as_tensor(frames)
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
             raise ValueError(f"frames should be uint8 [frames, height, width, 3], but got {frames.dtype} {tuple(frames.shape)}")
@@ -83,7 +87,11 @@ class ClipFrames:
         need = lib.avllm_clip_preproc_workspace_bytes(N, H, W, self.image)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out = torch.empty(N, 3, self.image, self.image, dtype=self.dtype, device=self.device)
+        if out is None:
+            out = torch.empty(N, 3, self.image, self.image, dtype=self.dtype, device=self.device)
+        elif out.numel() != N * 3 * self.image * self.image or out.dtype != self.dtype or not out.is_contiguous() or out.device != frames.device:
+            raise ValueError(f"out should be a contiguous {self.dtype} tensor of {N} x 3 x {self.image} x {self.image} elements on {frames.device}, "
+                             f"but got {out.dtype} {tuple(out.shape)}")
         L.check(lib.avllm_clip_preproc(L.ptr(plan), L.ptr(frames), N, H, W, self.image, L.ptr(out), L.dt_of(out), L.ptr(self._ws),
                                        self._ws.numel(), L.stream_ptr()))
         return out

@@ -31,7 +31,7 @@ int av_embedding(const void* table, const int64_t* ids, void* out, long n, int d
 int av_cast(const void* src, int sdt, void* dst, int ddt, long n, hipStream_t st);
 int av_whisper_im2col1(const float* mel, void* cols, int B, int n_mels, int T, int Kpad, int dtype, hipStream_t st);
 int av_whisper_im2col2(const void* h, void* cols, int B, int T, int d, int dtype, hipStream_t st);
-int av_clip_patchify(const float* frames, void* cols, int N, int S, int p, int Kpad, int dtype, hipStream_t st);
+int av_clip_patchify(const void* frames, void* cols, int N, int S, int p, int Kpad, int dtype, hipStream_t st, int in_dtype = AV_F32);
 int av_clip_cls_rows(const void* class_emb, const void* pos, void* x, int N, int tokens, int d, int dtype, hipStream_t st);
 int av_fuse_pool(const void* a, int Ta, const void* v, int Tv, const void* prompt_emb, int P, void* out, int B, int L,
                  int S_out, int D, float fs, int dtype, hipStream_t st);

@@ -200,8 +200,8 @@ __global__ void im2col2_kernel(const T* __restrict__ h, T* __restrict__ cols, in
 }
 
 // ---------------------------------------------------------------- CLIP patchify: coalesced along frame rows
-template <typename T, int V>                      // V pixels per thread: 4 when the patch width allows it, 2 for patch 14 (ViT-L/14), else 1
-__global__ void patchify_kernel(const float* __restrict__ fr, T* __restrict__ cols, int N, int S, int p, int Kpad) {
+template <typename T, int V, typename TI>         // V pixels per thread: 4 when the patch width allows it, 2 for patch 14 (ViT-L/14), else 1; TI = frame dtype
+__global__ void patchify_kernel(const TI* __restrict__ fr, T* __restrict__ cols, int N, int S, int p, int Kpad) {
     const int g = S / p, pp = p * p, SV = S / V;
     const long total = (long)N * 3 * S * SV;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -209,16 +209,16 @@ __global__ void patchify_kernel(const float* __restrict__ fr, T* __restrict__ co
         const int y = (int)((idx / SV) % S);
         const int c = (int)((idx / ((long)SV * S)) % 3);
         const long n = idx / ((long)SV * S * 3);
-        const float* src = fr + ((n * 3 + c) * S + y) * S + x;
+        const TI* src = fr + ((n * 3 + c) * S + y) * S + x;
         const int py = y / p, ky = y % p, px = x / p, kx = x % p;
         T* dst = cols + (n * g * g + (long)py * g + px) * Kpad + c * pp + ky * p + kx;
         if constexpr (V == 4) {
-            const f32x4 v = *(const f32x4*)src;
-            float o[4] = {v[0], v[1], v[2], v[3]};
+            float o[4];
+            load_f<4>(src, o);
             store_f<4>(dst, o);
         } else {
 #pragma unroll
-            for (int i = 0; i < V; ++i) dst[i] = from_f<T>(src[i]);
+            for (int i = 0; i < V; ++i) dst[i] = from_f<T>(to_f(src[i]));
         }
     }
 }
@@ -466,7 +466,7 @@ int av_whisper_im2col2(const void* h, void* cols, int B, int T, int d, int dtype
     return AV_OK;
 }
 
-int av_clip_patchify(const float* frames, void* cols, int N, int S, int p, int Kpad, int dtype, hipStream_t st) {
+int av_clip_patchify(const void* frames, void* cols, int N, int S, int p, int Kpad, int dtype, hipStream_t st, int in_dtype) {
     AV_CHECK_ARG(frames && cols && N > 0, "patchify: bad args");
     AV_CHECK_ARG(p > 0 && S % p == 0, "patchify: image %d is not a whole number of %d-pixel patches", S, p);
     const int K = 3 * p * p;
@@ -474,7 +474,8 @@ int av_clip_patchify(const float* frames, void* cols, int N, int S, int p, int K
     const int V = p % 4 == 0 ? 4 : p % 2 == 0 ? 2 : 1;
     const long total = (long)N * 3 * S * (S / V);
     const long rows = (long)N * (S / p) * (S / p);
-#define AV_PATCHIFY(T, VV) hipLaunchKernelGGL((patchify_kernel<T, VV>), dim3(grid_for(total)), dim3(256), 0, st, frames, (T*)cols, N, S, p, Kpad)
+#define AV_PATCHIFY(T, VV) do { if (in_dtype == AV_BF16) hipLaunchKernelGGL((patchify_kernel<T, VV, bf16>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)frames, (T*)cols, N, S, p, Kpad); \
+                                else hipLaunchKernelGGL((patchify_kernel<T, VV, float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)frames, (T*)cols, N, S, p, Kpad); } while (0)
     if (dtype == AV_F32) {
         if (V == 4) AV_PATCHIFY(float, 4); else if (V == 2) AV_PATCHIFY(float, 2); else AV_PATCHIFY(float, 1);
         if (Kpad > K) hipLaunchKernelGGL((patchify_pad_kernel<float>), dim3(grid_for(rows * (Kpad - K))), dim3(256), 0, st, (float*)cols, rows, K, Kpad);

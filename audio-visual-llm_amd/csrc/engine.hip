@@ -295,7 +295,7 @@ extern "C" size_t avllm_clip_workspace_bytes(const avllm_clip* c, int32_t N) {
     return bump_size(b);
 }
 
-extern "C" int avllm_clip_vision_cls_fwd(const avllm_clip* c, const float* frames, int32_t N, void* cls, void* ws,
+extern "C" int avllm_clip_vision_cls_fwd(const avllm_clip* c, const void* frames, int32_t N, void* cls, void* ws,
                                          size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AV_CHECK_ARG(c && frames && cls && ws && N > 0, "clip_vision_cls_fwd: null/empty");
@@ -308,7 +308,7 @@ extern "C" int avllm_clip_vision_cls_fwd(const avllm_clip* c, const float* frame
     if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "clip_vision_cls_fwd: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
     const int dt = c->dtype, d = c->d, np = g1 * g1;
     const size_t es = av_dtype_size(dt);
-    AV_TRY(av_clip_patchify(frames, s.cols, N, c->image, c->patch, kpad, dt, st));
+    AV_TRY(av_clip_patchify(frames, s.cols, N, c->image, c->patch, kpad, dt, st, c->frames_bf16 ? AV_BF16 : AV_F32));
     // patch embedding + position embedding of the patch tokens, scattered to rows 1.. of each frame
     avllm_gemm_desc g = gemm_desc(dt, s.cols, kpad, c->patch_w, kpad, s.e.xn, d, N * np, d, kpad);
     g.R = (const char*)c->pos + (size_t)d * es; g.ldr = d; g.r_mod = np;

@@ -67,6 +67,116 @@ def pmc_traffic_bytes():
     return None
 
 
+def pctl(ms):
+    """p10 / p50 / p90 of per-step GPU times (HIP events on the step's stream between consecutive steps)."""
+    v = sorted(ms)
+    q = lambda f: round(v[min(len(v) - 1, int(f * (len(v) - 1) + 0.5))], 3)
+    return {"p10": q(0.1), "p50": q(0.5), "p90": q(0.9), "n": len(v)}
+
+
+HBM_COPY_RATE = 6.29e12       # measured device-to-device copy rate of this part (DESIGN.md "Measured"), the bar decode is priced against
+
+
+def decode_bench(model, cfg, args, dev, B=8, new=48):
+    """Greedy decode as scripts/clip_whisper/decode.py runs it (LLM without adapters, clip_whisper_model.py:1337-1340): prefill on the 256 fused
+    AV positions, then `new` single-token steps on the KV cache.  A token step streams every frozen weight once: its floor is weight
+    bytes / HBM rate."""
+    eng = model.llm_engine
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = (torch.randn(B, 256, cfg.llama.hidden, generator=g, device=dev) * 0.02).to(eng.dtype)
+    ids = torch.randint(3, cfg.llama.vocab, (B,), generator=g, device=dev)
+    wbytes = eng.frozen_weight_bytes()
+    with eng.adapters_disabled():
+        kc, vc = eng.alloc_cache(B, 256 + new + 8)
+        eng.prefill(x, kc, vc)
+        for w in range(4):
+            eng.decode_step(ids, 256 + w, kc, vc)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in range(new):
+            eng.decode_step(ids, 260 + t, kc, vc)          # ids stay fixed (random weights): the arithmetic per step does not depend on them
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / new
+    return {"ms_per_token_step": round(ms, 3), "tok_s": round(B * 1000 / ms, 1), "hbm_frac": round(wbytes / (ms * 1e-3) / HBM_COPY_RATE, 4),
+            "batch": B, "context": "256 prefill + 4..52", "weight_bytes_per_step": int(wbytes), "hbm_rate": HBM_COPY_RATE / 1e12,
+            "note": "hbm_frac = frozen weight bytes streamed per token step / step time / measured copy rate (6.29 TB/s)"}
+
+
+def host_inputs_leg(args, cfg, model, trainer, labels, prompt, dev, rank, world, barrier):
+    """The step as the reference's DataLoader boundary feeds it (trainer/clip_whisper_trainer.py:604-723, data/simple_dataset.py:174-183,
+    :235-256): each batch arrives in PINNED HOST memory as raw uint8 RGB frames [B,F,224,224,3] + 16 kHz float samples [B,80000]; a copy
+    stream moves batch i+1 to the device (two staging sets) while step i computes; avllm_logmel / avllm_clip_preproc (bf16 out) write the
+    captured step's input buffers; then the step.  Everything is inside the timed region."""
+    from avllm.preprocess import ClipFrames, WhisperLogMel
+    B, Fr, S = args.batch, args.frames, cfg.clip.image
+    nsamp = int(16000 * Fr / 25)
+    g = torch.Generator().manual_seed(99 + rank)
+    host = []
+    for _ in range(2):                                   # two distinct pinned batches, cycled (a DataLoader with pin_memory=True hands over such buffers)
+        fr = torch.randint(0, 256, (B, Fr, S, S, 3), generator=g, dtype=torch.uint8).pin_memory()
+        wv = (torch.randn(B, nsamp, generator=g) * 0.1).pin_memory()
+        host.append((fr, wv))
+    stage = [(torch.empty((B, Fr, S, S, 3), dtype=torch.uint8, device=dev), torch.empty((B, nsamp), dtype=torch.float32, device=dev)) for _ in range(2)]
+    logmel = WhisperLogMel(device=dev, n_mels=cfg.whisper.n_mels)
+    frames = ClipFrames(device=dev, image=S, dtype=torch.bfloat16)
+    audio = torch.empty(B, cfg.whisper.n_mels, 3000, dtype=torch.float32, device=dev)
+    video = torch.empty(B, Fr, 3, S, S, dtype=torch.bfloat16, device=dev)
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    copied = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        k = i % 2
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[k])          # the preprocessing that last read this staging set
+            stage[k][0].copy_(host[k][0], non_blocking=True)
+            stage[k][1].copy_(host[k][1], non_blocking=True)
+            copied[k].record(copy_stream)
+
+    def step(i, a, v):
+        k = i % 2
+        upload(i + 1)
+        main.wait_event(copied[k])
+        logmel(stage[k][1], out=a)
+        frames(stage[k][0].view(B * Fr, S, S, 3), out=v)
+        consumed[k].record(main)
+        return trainer.train_step(a, v, labels, prompt)
+
+    for k in range(2):
+        consumed[k].record(main)
+    upload(0)
+    step(0, audio, video)                                # eager (sizes), capture, then the captured step's own buffers
+    step(1, audio, video)
+    si = trainer.static_inputs(audio, video, labels, prompt)
+    if si is not None:
+        audio, video, labels, prompt = si
+    step(2, audio, video)
+    n = args.steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(n):
+        marks[i].record()
+        loss = step(3 + i, audio, video)
+    marks[n].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    copy_stream.synchronize()
+    h2d = B * Fr * S * S * 3 + B * nsamp * 4
+    return {"value": round(B * world * n / dt, 4), "unit": "samples/s", "ms_per_step": round(1000 * dt / n, 3),
+            "step_ms": pctl([marks[i].elapsed_time(marks[i + 1]) for i in range(n)]), "steps": n,
+            "h2d_bytes_per_step": h2d, "final_loss": round(float(loss), 5),
+            "path": "pinned host uint8 frames [B,F,224,224,3] + f32 16 kHz samples -> H2D on a copy stream (2 staging sets, batch i+1 under step i) -> "
+                    "avllm_logmel (f32) + avllm_clip_preproc (bf16 pixel_values) into the captured step's input buffers -> train step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +189,10 @@ def main():
                     "projections of the forward pass; use with --whisper openai/whisper-large-v3 --clip openai/clip-vit-large-patch14 "
                     "--llm mistralai/Mistral-7B-v0.1 --frames 750)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"], help="sample: bounded slice of one B=1 step scaled up (default, ~20 s); "
+                    "full: one complete B=1 train step of the oracle at full depth (~1-2 min of host time)")
+    ap.add_argument("--no-host-inputs", action="store_true", help="skip the second leg (batches arriving in pinned host memory as raw uint8 frames + samples)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
@@ -150,8 +264,12 @@ def main():
     # eagerly (events cannot bracket single kernels of a graph replay) and a bracketed launch costs ~6 us of idle GPU (two barrier
     # packets): they stay inside the timed region and cost the reported throughput ~0.5 %
     sampled = 0
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
+        if i:
+            marks[i].record()
         if timing:
             on = i % TIMING_EVERY == 0
             L.check(lib.avllm_profile_enable(1 if on else 0))
@@ -159,8 +277,10 @@ def main():
             loss = trainer.train_step(audio, video, labels, prompt, graph=not on)
             continue
         loss = trainer.train_step(audio, video, labels, prompt)
+    marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     prof = (ctypes.c_double * 4)()
     if timing:
         L.check(lib.avllm_profile_end(prof))
@@ -169,6 +289,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     final_loss = float(loss)
+    host_leg = None
+    if not args.no_host_inputs and not args.tiny:
+        host_leg = host_inputs_leg(args, cfg, model, trainer, labels, prompt, dev, rank, world, barrier)
+    decode_leg = None
+    if rank == 0 and world == 1 and not args.no_decode and not args.tiny:
+        decode_leg = decode_bench(model, cfg, args, dev)
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
@@ -180,8 +306,13 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: " if default_llm and not args.tiny else "variant (not the BASELINE config): ") + f"{name}, synthetic LRS3-shaped {args.frames / 25:g} s clips ({args.frames} frames), "
                                    f"max_seq_len {args.max_seq_len}, train seq 256", "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "samples_per_s_per_gpu": round(value / world, 4),
-                       "final_loss": round(final_loss, 5), "launch": "hipGraph replay" if use_graph else "eager"},
+                       "final_loss": round(final_loss, 5), "launch": "hipGraph replay" if use_graph else "eager",
+                       "step_ms": pctl(step_ms), "inputs": "resident in HBM: fp32 log-mel [B,80,3000] + fp32 pixel_values [B,frames,3,224,224] (the reference model's arguments)"},
         }
+        if host_leg is not None:
+            out["config"]["host_inputs"] = host_leg
+        if decode_leg is not None:
+            out["decode"] = decode_leg
         frac_e2e = value / world * FLOP_PER_CLIP / MFMA_BF16_PEAK
         peak = MFMA_FP8_PEAK if args.precision == "fp8" else MFMA_BF16_PEAK
         if timing and prof[2] > 0:
@@ -200,7 +331,7 @@ def main():
                                "unit": "TFLOP/s", "frac": round(frac_e2e, 4), "traffic": None}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_baseline
-            out["cpu_baseline"] = cpu_baseline.run(frames=args.frames)
+            out["cpu_baseline"] = cpu_baseline.run_full(frames=args.frames) if args.cpu_baseline == "full" else cpu_baseline.run(frames=args.frames)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

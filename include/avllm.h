@@ -279,11 +279,13 @@ typedef struct avllm_clip {
     const void *pre_ln_w, *pre_ln_b;
     const avllm_enc_layer* layer;    /* host array [layers] */
     int32_t fp8;                     /* as avllm_whisper.fp8 */
+    int32_t frames_bf16;             /* 1: `frames` of avllm_clip_vision_cls_fwd are bf16 (what avllm_clip_preproc writes with dtype bf16: half the bytes
+                                      * of the reference's fp32 pixel_values on the way into the patch embedding) */
 } avllm_clip;
 size_t avllm_clip_workspace_bytes(const avllm_clip* c, int32_t N);
 /* ClipWhisperModel.encode_video minus the connector (clip_whisper_model.py:1108-1142 -> CLIPVisionModel.forward,
  * last_hidden_state[:,0], no post_layernorm): frames f32 [N,3,S,S] -> cls [N,d] */
-int avllm_clip_vision_cls_fwd(const avllm_clip* c, const float* frames, int32_t N, void* cls, void* ws,
+int avllm_clip_vision_cls_fwd(const avllm_clip* c, const void* frames, int32_t N, void* cls, void* ws,
                               size_t ws_bytes, void* stream);
 
 typedef struct avllm_lora_mod {      /* padded operand images (see avllm_lora_pack); NULL = no adapter */

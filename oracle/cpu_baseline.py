@@ -66,6 +66,45 @@ def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 
     }
 
 
+def run_full(cfg: Wt.ModelCfg | None = None, frames: int = 125, threads: int | None = None):
+    """ONE complete B=1 train step of the oracle at full depth and width (BASELINE.md §2 protocol, minus the optimizer's microseconds):
+    every encoder layer, every frame, all decoder layers forward and backward.  The 32 decoder layers share ONE set of random tensors
+    (same arithmetic and cache behaviour per layer, 1/32 of the 27 GB an fp32 Llama-2-7B would need on the host)."""
+    cfg = cfg or Wt.config2()
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    t_all = time.time()
+    one = Wt.LlamaCfg(**{**vars(cfg.llama), "layers": 1})
+    L1 = Wt.llama_weights(one, 0)
+    llama = {k: v for k, v in L1.items() if "layers." not in k}
+    lora1 = Wt.lora_weights(one, cfg.lora, 0, 0.01)
+    lora = {}
+    for i in range(cfg.llama.layers):
+        for k, v in L1.items():
+            if k.startswith("model.layers.0."):
+                llama[k.replace("model.layers.0.", f"model.layers.{i}.")] = v
+        for k, v in lora1.items():
+            lora[k.replace("layers.0.", f"layers.{i}.")] = v.clone()
+    W = {"whisper": Wt.whisper_weights(cfg.whisper, 0), "clip": Wt.clip_weights(cfg.clip, 0), "llama": llama, "lora": lora,
+         "audio_connector": Wt.connector_weights(cfg.whisper.d_model, cfg.llama.hidden, "conn.audio", 0),
+         "video_connector": Wt.connector_weights(cfg.clip.hidden, cfg.llama.hidden, "conn.video", 0)}
+    audio, video, labels, prompt = Wt.synthetic_batch(cfg, 1, frames, seed=1234)
+    t_setup = time.time() - t_all
+    split = {}
+    with torch.no_grad():
+        t0 = time.time(); O.whisper_encoder(W["whisper"], cfg.whisper, audio); split["whisper"] = round(time.time() - t0, 3)
+        t0 = time.time(); O.clip_vision_cls(W["clip"], cfg.clip, video.reshape(-1, 3, cfg.clip.image, cfg.clip.image)); split["clip"] = round(time.time() - t0, 3)
+    t0 = time.time()
+    O.train_step_grads(W, cfg, audio, video, prompt, labels)
+    step_s = time.time() - t0
+    split["llama_fwd_bwd"] = round(step_s - split["whisper"] - split["clip"], 3)
+    return {"value": 1.0 / step_s, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"one full B=1 train step ({frames} frames, all {cfg.whisper.layers}+{cfg.clip.layers}+{cfg.llama.layers} layers, forward + backward), fp32 torch CPU "
+                      "oracle; the decoder layers share one set of random tensors", "split_s": split, "measured_s": round(time.time() - t_all, 2),
+            "setup_s": round(t_setup, 2)}
+
+
 if __name__ == "__main__":
     import json
-    print(json.dumps(run()))
+    import sys
+    print(json.dumps(run_full() if "--full" in sys.argv else run()))
