@@ -391,11 +391,14 @@ class LlamaEngine:
                                         L.ptr(ws), ws.numel(), L.stream_ptr()))
         return last, full
 
-    def decode_step(self, ids, pos, kc, vc):
+    def decode_step(self, ids, pos, kc, vc, pos_dev=None, logits=None):
+        """One token per sequence at position `pos` (+ the int32 in device memory `pos_dev`: a captured step replays for every token).
+        `logits`: optional preallocated [B, vocab] float32 output."""
         lib = L.load()
         B = ids.shape[0]
         ws = self.ws_infer.get(lib.avllm_llama_infer_workspace_bytes(C.byref(self.desc), B, 1))
-        logits = torch.empty(B, self.cfg.vocab, device=self.device, dtype=torch.float32)
-        L.check(lib.avllm_llama_decode_step(C.byref(self.desc), L.ptr(ids.contiguous()), B, pos, L.ptr(kc), L.ptr(vc), kc.shape[2],
-                                            L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        if logits is None:
+            logits = torch.empty(B, self.cfg.vocab, device=self.device, dtype=torch.float32)
+        L.check(lib.avllm_llama_decode_step_at(C.byref(self.desc), L.ptr(ids.contiguous()), B, pos, L.ptr(pos_dev), L.ptr(kc), L.ptr(vc), kc.shape[2],
+                                               L.ptr(logits), L.ptr(ws), ws.numel(), L.stream_ptr()))
         return logits

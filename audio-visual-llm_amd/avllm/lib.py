@@ -67,6 +67,13 @@ class GemmF8Desc(C.Structure):
                 ("ldr", i64), ("M", i32), ("N", i32), ("K", i32), ("act", i32)]
 
 
+class DecProjDesc(C.Structure):
+    """avllm_dec_proj_desc (include/avllm.h): one projection of a decode token step."""
+    _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("norm_w", vp), ("eps", f32), ("M", i32), ("K", i32), ("N", i32), ("mode", i32),
+                ("C", vp), ("ldc", i64), ("out_f32", i32), ("R", vp), ("ldr", i64), ("dq", i32), ("dkv", i32), ("hd", i32), ("rope", vp),
+                ("kc", vp), ("vc", vp), ("Tmax", i32), ("pos", i32), ("pos_dev", vp)]
+
+
 class StepState(C.Structure):
     """avllm_step_state: per-step scalars in DEVICE memory (this mirror is only used for sizes / field offsets / host reads)."""
     _fields_ = [("step", C.c_uint32), ("dropout_seed", C.c_uint32), ("lr", f32), ("bc1", f32), ("bc2_sqrt", f32), ("skipped", f32),
@@ -137,6 +144,10 @@ _SIGS = {
     "avllm_llama_infer_workspace_bytes": ([C.POINTER(Llama), i32, i32], sz),
     "avllm_llama_prefill": ([C.POINTER(Llama), vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp], i32),
     "avllm_llama_decode_step": ([C.POINTER(Llama), vp, i32, i32, vp, vp, i32, vp, vp, sz, vp], i32),
+    "avllm_llama_decode_step_at": ([C.POINTER(Llama), vp, i32, i32, vp, vp, vp, i32, vp, vp, sz, vp], i32),
+    "avllm_pos_advance": ([vp, i32, vp], i32),
+    "avllm_dec_proj": ([C.POINTER(DecProjDesc), vp], i32),
+    "avllm_attention_decode": ([vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, f32, i32, i32, vp], i32),
 }
 
 EXPORTS = sorted(list(_SIGS) + ["avllm_last_error"])

@@ -45,7 +45,11 @@ int av_kv_append(const void* k, const void* v, long ld, void* kc, void* vc, int 
                  int dtype, hipStream_t st);
 int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st, int G = 1);
-int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st);
+int av_attention_decode1(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd, int Tk, const int* tk_dev,
+                         int Tmax, float scale, int dtype, hipStream_t st, int G);
+bool av_dec_proj_supported(int dtype, int M, int K, int N, int mode, int hd);
+int av_dec_proj(const avllm_dec_proj_desc* d, hipStream_t st);
+int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev = nullptr);
 int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);
 int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st, const uint32_t* seed_dev = nullptr);
 bool av_lora_dx_masked_supported(int dtype, int N, int r, const long* ldt, const long* ldat, int nj, long ldr, long ldo);

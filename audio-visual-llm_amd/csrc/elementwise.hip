@@ -36,8 +36,9 @@ __global__ void rope_kernel(T* __restrict__ x, long ld, long rows, int T_, int h
 }
 
 // cos/sin table [T][hd/2][2] for positions pos0..pos0+T-1 (computed once per call instead of per element per layer)
-__global__ void rope_table_kernel(float* __restrict__ tab, int T_, int hd, int pos0, float theta) {
+__global__ void rope_table_kernel(float* __restrict__ tab, int T_, int hd, int pos0, float theta, const int* __restrict__ pos_dev) {
     const int half = hd >> 1;
+    if (pos_dev) pos0 += *pos_dev;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T_ * half) return;
     const int i = idx % half, t = idx / half;
@@ -378,9 +379,9 @@ int av_rope(void* x, long ld, long rows, int T, int heads, int hd, int pos0, flo
     return AV_OK;
 }
 
-int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st) {
+int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev) {
     AV_CHECK_ARG(tab && T > 0 && hd % 8 == 0, "rope_table: bad args");
-    hipLaunchKernelGGL(rope_table_kernel, dim3(av_cdiv((long)T * (hd / 2), 256)), dim3(256), 0, st, tab, T, hd, pos0, theta);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(av_cdiv((long)T * (hd / 2), 256)), dim3(256), 0, st, tab, T, hd, pos0, theta, pos_dev);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -642,20 +642,73 @@ extern "C" int avllm_llama_prefill(const avllm_llama* m, const void* x, int32_t 
     return AV_OK;
 }
 
-extern "C" int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, void* kcache,
-                                       void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream) {
+// One decoder block of a token step in 5 launches (decode.hip): bf16, B <= 16 sequences, no adapters on this layer.
+static bool llama_decode_fused_ok(const avllm_llama* m, int B) {
+    const bool off = getenv("AVLLM_DECODE_FUSED") && atoi(getenv("AVLLM_DECODE_FUSED")) == 0;
+    if (off || m->dtype != AV_BF16 || B > 16) return false;
+    const int hd = m->d / m->heads;
+    if (!(hd == 64 || hd == 128)) return false;
+    if (!av_dec_proj_supported(AV_BF16, B, m->d, llama_qw(m), 2, hd) || !av_dec_proj_supported(AV_BF16, B, m->d, m->ffn, 1, hd) ||
+        !av_dec_proj_supported(AV_BF16, B, m->ffn, m->d, 0, hd) || !av_dec_proj_supported(AV_BF16, B, m->d, m->d, 0, hd)) return false;
+    for (int l = 0; l < m->layers; ++l)
+        for (int j = 0; j < 4; ++j)
+            if (m->layer[l].lora[j].A_pad) return false;          // adapters: the general path (lora_proj)
+    return true;
+}
+
+static int llama_decode_layer_fused(const avllm_llama* m, int l, LlamaInferWs& w, int B, int pos, const int* pos_dev, void* kc, void* vc, int Tmax,
+                                    hipStream_t st) {
+    const avllm_llama_layer& P = m->layer[l];
+    const int d = m->d, f = m->ffn, H = m->heads, hd = d / H, Hkv = llama_kv_heads(m), dkv = llama_dkv(m), qw = llama_qw(m);
+    char* kcl = (char*)kc + (size_t)l * B * Tmax * dkv * 2;
+    char* vcl = (char*)vc + (size_t)l * B * Tmax * dkv * 2;
+    avllm_dec_proj_desc p = {};
+    p.A = w.x; p.lda = d; p.W = P.wqkv; p.ldw = d; p.norm_w = P.ln1_w; p.eps = m->eps; p.M = B; p.K = d; p.N = qw; p.mode = 2;
+    p.C = w.qkv; p.ldc = qw; p.dq = d; p.dkv = dkv; p.hd = hd; p.rope = w.rope_tab; p.kc = kcl; p.vc = vcl; p.Tmax = Tmax; p.pos = pos; p.pos_dev = pos_dev;
+    AV_TRY(av_dec_proj(&p, st));
+    AV_TRY(av_attention_decode1(w.qkv, qw, kcl, vcl, w.att, d, B, H, hd, pos + 1, pos_dev, Tmax, 1.0f / sqrtf((float)hd), AV_BF16, st, H / Hkv));
+    p = {};
+    p.A = w.att; p.lda = d; p.W = P.wo; p.ldw = d; p.M = B; p.K = d; p.N = d; p.mode = 0; p.C = w.x; p.ldc = d; p.R = w.x; p.ldr = d;
+    AV_TRY(av_dec_proj(&p, st));
+    p = {};
+    p.A = w.x; p.lda = d; p.W = P.wgu; p.ldw = d; p.norm_w = P.ln2_w; p.eps = m->eps; p.M = B; p.K = d; p.N = f; p.mode = 1; p.C = w.hmid; p.ldc = f;
+    AV_TRY(av_dec_proj(&p, st));
+    p = {};
+    p.A = w.hmid; p.lda = f; p.W = P.wdown; p.ldw = f; p.M = B; p.K = f; p.N = d; p.mode = 0; p.C = w.x; p.ldc = d; p.R = w.x; p.ldr = d;
+    return av_dec_proj(&p, st);
+}
+
+extern "C" int avllm_llama_decode_step_at(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, const int32_t* pos_dev, void* kcache,
+                                          void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AV_TRY(check_llama(m));
-    AV_CHECK_ARG(ids && kcache && vcache && logits && ws && B > 0 && pos >= 0 && pos < Tmax, "llama_decode_step: bad args (pos=%d Tmax=%d)", pos, Tmax);
+    AV_CHECK_ARG(ids && kcache && vcache && logits && ws && B > 0 && pos >= 0 && (pos_dev || pos < Tmax), "llama_decode_step: bad args (pos=%d Tmax=%d)", pos, Tmax);
     Bump b(ws, ws_bytes);
     LlamaInferWs w;
     carve_llama_infer(m, B, 1, b, w, true);
     if (!b.ok) return av_set_error(AV_ERR_WORKSPACE, "llama_decode_step: workspace %zu < %zu bytes", ws_bytes, bump_size(b));
     const int dt = m->dtype, d = m->d;
     AV_TRY(av_embedding(m->embed, ids, w.x, B, d, dt, st));
-    for (int l = 0; l < m->layers; ++l) AV_TRY(llama_infer_layer(m, l, w, B, 1, pos, kcache, vcache, Tmax, st));
+    if (llama_decode_fused_ok(m, B)) {
+        AV_TRY(av_rope_table(w.rope_tab, 1, d / m->heads, pos, m->theta, st, pos_dev));
+        for (int l = 0; l < m->layers; ++l) AV_TRY(llama_decode_layer_fused(m, l, w, B, pos, pos_dev, kcache, vcache, Tmax, st));
+        if (av_dec_proj_supported(AV_BF16, B, d, m->vocab, 0, 0)) {          // final norm folded into the lm_head stream
+            avllm_dec_proj_desc p = {};
+            p.A = w.x; p.lda = d; p.W = m->lm_head; p.ldw = d; p.norm_w = m->norm_w; p.eps = m->eps; p.M = B; p.K = d; p.N = m->vocab; p.mode = 0;
+            p.C = logits; p.ldc = m->vocab; p.out_f32 = 1;
+            return av_dec_proj(&p, st);
+        }
+    } else {
+        AV_CHECK_ARG(!pos_dev, "llama_decode_step: a device-side position needs the fused bf16 token step (B <= 16, no adapters)");
+        for (int l = 0; l < m->layers; ++l) AV_TRY(llama_infer_layer(m, l, w, B, 1, pos, kcache, vcache, Tmax, st));
+    }
     AV_TRY(av_rmsnorm_fwd(w.x, m->norm_w, w.xn, nullptr, B, d, m->eps, dt, st));
     avllm_gemm_desc g = gemm_desc(dt, w.xn, d, m->lm_head, d, logits, m->vocab, B, m->vocab, d);
     g.out_f32 = 1;
     return av_gemm(&g, st);
+}
+
+extern "C" int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, void* kcache,
+                                       void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream) {
+    return avllm_llama_decode_step_at(m, ids, B, pos, nullptr, kcache, vcache, Tmax, logits, ws, ws_bytes, stream);
 }

@@ -363,6 +363,38 @@ int avllm_llama_prefill(const avllm_llama* m, const void* x, int32_t B, int32_t 
                         int32_t Tmax, float* logits_last, void* all_logits, void* ws, size_t ws_bytes, void* stream);
 int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, void* kcache,
                             void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream);
+/* The same step with the position in DEVICE memory: the token runs at position pos + *pos_dev (pos_dev may be NULL), so a captured
+ * hipGraph of the step can be replayed for every token (advance *pos_dev between replays, e.g. with avllm_step_advance's sibling
+ * avllm_pos_advance).  The caller guarantees pos + *pos_dev < Tmax. */
+int avllm_llama_decode_step_at(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, const int32_t* pos_dev, void* kcache,
+                               void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream);
+int avllm_pos_advance(int32_t* pos_dev, int32_t by, void* stream);
+
+/* One projection of a decode token step (bf16, 1 <= M <= 16 rows, K % 128 == 0): C = epilogue(rmsnorm?(A) . W^T).  Every weight row
+ * is streamed from HBM once; the fused forms remove the launches between the projections of LlamaDecoderLayer.forward:
+ *   mode 0  plain: C[M,N] (+ R), bf16 or f32 out                                    (o_proj / down_proj + residual, lm_head)
+ *   mode 1  SwiGLU: W = [gate; up] rows [2N, K]; C[M,N] = silu(A.gate^T) * (A.up^T)  (LlamaMLP.forward's act_fn(gate) * up)
+ *   mode 2  q|k|v: W rows [dq + 2 dkv, K]; rotary embedding on q and k (pairs (i, i + hd/2), table rope[hd/2][2] = cos,sin of the
+ *           position); q -> C[M,dq]; k, v -> cache rows kc/vc[m][pos + *pos_dev][dkv]  (apply_rotary_pos_emb + DynamicCache.update)
+ * norm_w != NULL folds the preceding RMSNorm in: x * rsqrt(mean(x^2) + eps) * norm_w is applied to A on the fly. */
+typedef struct avllm_dec_proj_desc {
+    const void* A; int64_t lda;
+    const void* W; int64_t ldw;
+    const void* norm_w; float eps;
+    int32_t M, K, N, mode;
+    void* C; int64_t ldc; int32_t out_f32;
+    const void* R; int64_t ldr;
+    int32_t dq, dkv, hd;
+    const float* rope;
+    void *kc, *vc;
+    int32_t Tmax, pos;
+    const int32_t* pos_dev;
+} avllm_dec_proj_desc;
+int avllm_dec_proj(const avllm_dec_proj_desc* d, void* stream);
+/* Single-query attention over the cache rows [0, Tk + *tk_dev) (tk_dev may be NULL) of kc/vc [B][Tmax][(H/kv_group)*hd]: one pass with
+ * an online softmax; q [B, H*hd] (row stride ldq), o [B, H*hd] (ldo).  LlamaAttention.forward with q_len == 1 (eager softmax(QK^T/sqrt(hd))V). */
+int avllm_attention_decode(const void* q, int64_t ldq, const void* kc, const void* vc, void* o, int64_t ldo, int32_t B, int32_t H, int32_t hd,
+                           int32_t Tk, const int32_t* tk_dev, int32_t Tmax, float scale, int32_t kv_group, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

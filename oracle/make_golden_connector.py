@@ -25,12 +25,12 @@ def main():
     for tag, layers, name in (("a", 2, "deep"), ("b", 4, "qformer")):          # "qformer" is not in the factory's map -> deep
         torch.manual_seed(11 + layers)
         kw = dict(device="cpu", dtype=torch.float32, num_layers=layers)
-        conn = mc.create_modality_connector(name, 48, 96, **kw)
+        conn = mc.create_modality_connector(name, 64, 128, **kw)
         assert type(conn).__name__ == "DeepModalityConnector"
         for p in conn.parameters():                                            # non-trivial biases / norm weights so every term is exercised
             if p.dim() == 1:
                 p.data.add_(0.1 * torch.randn_like(p))
-        x = torch.randn(2, 9, 48)
+        x = torch.randn(2, 9, 64)
         with torch.no_grad():
             y = conn(x)
         sd = {k: v.detach().clone() for k, v in conn.state_dict().items()}

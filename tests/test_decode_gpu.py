@@ -1,0 +1,172 @@
+"""Greedy-decode token step (clip_whisper_model.py:1337-1340 -> LlamaDecoderLayer.forward with q_len == 1): the fused projections
+(avllm_dec_proj: RMSNorm in the A operand, RoPE + cache append / SwiGLU / residual in the epilogue), the single-pass cache attention and the
+whole step, against plain torch fp32 arithmetic on the same bf16 inputs.  Floating point: bars are bf16's (tests/bars.py)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from avllm import ops  # noqa: E402
+from bars import BF16_LOGITS_REL_L2, rel_l2  # noqa: E402
+from test_ops_gpu import rnd  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def rms(x, w, eps):
+    x = x.float()
+    return x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps) * w.float()
+
+
+# K / 128 units dealt to the 8 waves: 1 (one wave works), 3, 9 (two groups on one wave), 23 (odd / even group counts mixed: 3,3,3,3,3,3,3,2),
+# 32 (4096: four groups each), 86 (11008: 11 / 10)
+@pytest.mark.parametrize("K", [128, 384, 1152, 2944, 4096, 11008])
+@pytest.mark.parametrize("M", [1, 8, 16])
+def test_dec_proj_plain_norm_residual(dev, M, K):
+    N = 528
+    A, W = rnd(M, K, dtype=BF, seed=1), rnd(N, K, dtype=BF, seed=2, scale=K ** -0.5)
+    R, g = rnd(M, N, dtype=BF, seed=3), (1.0 + 0.1 * rnd(K, dtype=torch.float32, seed=4)).to(BF)
+    ref = A.float() @ W.float().t()
+    assert rel_l2(ops.dec_proj(A, W, out_f32=True), ref) < 2e-3                      # bf16 products, fp32 accumulate: only summation order differs
+    out = R.clone()
+    ops.dec_proj(A, W, R=out, out=out)                                               # in-place residual (o_proj / down_proj)
+    assert rel_l2(out, ref + R.float()) < 6e-3
+    refn = rms(A, g, 1e-5) @ W.float().t()
+    assert rel_l2(ops.dec_proj(A, W, norm_w=g, eps=1e-5, out_f32=True), refn) < 6e-3  # the normed operand is rounded to bf16 once, like the unfused path's xn
+    rows = rnd(4 * M, K, dtype=BF, seed=5)                                           # strided A rows
+    assert rel_l2(ops.dec_proj(rows[3::4], W, out_f32=True), rows[3::4].float() @ W.float().t()) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,F", [(1, 256, 64), (8, 4096, 11008), (16, 1152, 520)])
+def test_dec_proj_swiglu(dev, M, K, F):
+    A, W = rnd(M, K, dtype=BF, seed=11), rnd(2 * F, K, dtype=BF, seed=12, scale=K ** -0.5)
+    g = (1.0 + 0.1 * rnd(K, dtype=torch.float32, seed=13)).to(BF)
+    xn = rms(A, g, 1e-6)
+    gate, up = xn @ W[:F].float().t(), xn @ W[F:].float().t()
+    out = ops.dec_proj(A, W, mode=1, norm_w=g, eps=1e-6)
+    assert out.shape == (M, F) and rel_l2(out, torch.nn.functional.silu(gate) * up) < 8e-3
+
+
+@pytest.mark.parametrize("M,heads,kvh,hd,K", [(2, 4, 4, 128, 512), (8, 4, 2, 64, 256), (16, 8, 2, 128, 1024), (3, 32, 32, 128, 4096)])
+def test_dec_proj_qkv_rope_cache(dev, M, heads, kvh, hd, K):
+    """q|k|v projection with RoPE (HF rotate_half pairing (i, i + hd/2)) and the k/v rows written into the cache at `pos` (+ *pos_dev);
+    every other cache row must stay untouched."""
+    dq, dkv, Tmax, pos = heads * hd, kvh * hd, 9, 5
+    A, W = rnd(M, K, dtype=BF, seed=21), rnd(dq + 2 * dkv, K, dtype=BF, seed=22, scale=K ** -0.5)
+    g = (1.0 + 0.1 * rnd(K, dtype=torch.float32, seed=23)).to(BF)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    ang = pos * inv
+    rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    y = rms(A, g, 1e-5) @ W.float().t()
+
+    def rot(t, nh):
+        t = t.view(M, nh, hd)
+        a, b = t[..., : hd // 2], t[..., hd // 2:]
+        return torch.cat([a * ang.cos() - b * ang.sin(), b * ang.cos() + a * ang.sin()], -1).reshape(M, nh * hd)
+
+    for use_dev in (False, True):
+        kc = torch.full((M, Tmax, dkv), 7.0, device=dev, dtype=BF)
+        vc = torch.full((M, Tmax, dkv), -7.0, device=dev, dtype=BF)
+        pd = torch.tensor([3], device=dev, dtype=torch.int32) if use_dev else None
+        q = ops.dec_proj(A, W, mode=2, norm_w=g, eps=1e-5, rope=rope, kc=kc, vc=vc, pos=pos - (3 if use_dev else 0), pos_dev=pd, dq=dq, dkv=dkv, hd=hd)
+        assert rel_l2(q, rot(y[:, :dq], heads)) < 8e-3
+        assert rel_l2(kc[:, pos], rot(y[:, dq:dq + dkv], kvh)) < 8e-3
+        assert rel_l2(vc[:, pos], y[:, dq + dkv:]) < 8e-3
+        keep = [t for t in range(Tmax) if t != pos]
+        assert (kc[:, keep] == 7.0).all() and (vc[:, keep] == -7.0).all()
+
+
+def test_dec_proj_refuses_what_it_cannot_do(dev):
+    A, W = rnd(17, 256, dtype=BF, seed=1), rnd(64, 256, dtype=BF, seed=2)
+    with pytest.raises(ValueError):
+        ops.dec_proj(A, W)                                       # 17 rows
+    with pytest.raises(ValueError):
+        ops.dec_proj(A[:4, :192], W[:, :192])                    # K % 128
+    with pytest.raises(ValueError):
+        ops.dec_proj(A[:4], W[:60])                              # N % 16
+
+
+@pytest.mark.parametrize("B,H,Hkv,hd,Tk,dtype", [(2, 4, 4, 128, 1, BF), (8, 32, 32, 128, 300, BF), (3, 8, 2, 64, 700, BF), (16, 128, 16, 64, 130, BF),
+                                                   (2, 4, 2, 128, 257, torch.float32)])
+def test_attention_decode_single_pass(dev, B, H, Hkv, hd, Tk, dtype):
+    """One pass with an online softmax; (8,32,..,300) is the decode bench's shape (two trips, the second ragged), (16,128,..) takes the 4-wave
+    instantiation (B*H > 1024), Tk = 1 leaves most row groups empty (-inf merge)."""
+    Tmax = Tk + 5
+    q = rnd(B, H * hd, dtype=dtype, seed=31)
+    kc, vc = rnd(B, Tmax, Hkv * hd, dtype=dtype, seed=32), rnd(B, Tmax, Hkv * hd, dtype=dtype, seed=33)
+    kc[:, Tk:] = float("nan")                                    # rows past Tk must never be read into the result
+    vc[:, Tk:] = float("nan")
+    rep = H // Hkv
+    qf = q.float().view(B, H, 1, hd)
+    kf = kc[:, :Tk].float().view(B, Tk, Hkv, hd).permute(0, 2, 1, 3).repeat_interleave(rep, 1)
+    vf = vc[:, :Tk].float().view(B, Tk, Hkv, hd).permute(0, 2, 1, 3).repeat_interleave(rep, 1)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf).reshape(B, H * hd)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_l2(ops.attention_decode(q, kc, vc, H, Tk), ref) < tol
+    td = torch.tensor([Tk - 1], device=dev, dtype=torch.int32)
+    assert rel_l2(ops.attention_decode(q, kc, vc, H, 1, tk_dev=td), ref) < tol
+
+
+def _engine(dev, hidden, heads, kvh, layers, ffn, vocab, seed=5):
+    from avllm.arch import LlamaCfg
+    from avllm.engine import LlamaEngine
+    cfg = LlamaCfg(hidden, heads, layers, ffn, vocab)
+    cfg.kv_heads = kvh
+    g = torch.Generator().manual_seed(seed)
+    dkv = kvh * (hidden // heads)
+    sd = {"model.embed_tokens.weight": torch.randn(vocab, hidden, generator=g) * 0.5, "model.norm.weight": 1 + 0.1 * torch.randn(hidden, generator=g),
+          "lm_head.weight": torch.randn(vocab, hidden, generator=g) * hidden ** -0.5}
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        for nm, (o, k) in {"self_attn.q_proj": (hidden, hidden), "self_attn.k_proj": (dkv, hidden), "self_attn.v_proj": (dkv, hidden),
+                           "self_attn.o_proj": (hidden, hidden), "mlp.gate_proj": (ffn, hidden), "mlp.up_proj": (ffn, hidden),
+                           "mlp.down_proj": (hidden, ffn)}.items():
+            sd[p + nm + ".weight"] = torch.randn(o, k, generator=g) * k ** -0.5
+        sd[p + "input_layernorm.weight"] = 1 + 0.1 * torch.randn(hidden, generator=g)
+        sd[p + "post_attention_layernorm.weight"] = 1 + 0.1 * torch.randn(hidden, generator=g)
+    return LlamaEngine(sd, cfg, None, None, dtype=BF, device=dev, training=False), cfg
+
+
+@pytest.mark.parametrize("hidden,heads,kvh,B", [(256, 2, 2, 3), (512, 8, 2, 8)])
+def test_token_step_fused_matches_general_path_and_prefill(dev, hidden, heads, kvh, B):
+    """The 5-launch token step against (a) the general 10-launch path on the same cache (AVLLM_DECODE_FUSED=0) and (b) a prefill that
+    recomputes every position: logits of position S from `prefill(S) + step` vs `prefill(S + 1)`; then three more steps with the
+    position taken from device memory (what a captured step replays)."""
+    eng, cfg = _engine(dev, hidden, heads, kvh, 2, 384, 256)
+    S, new = 37, 4
+    g = torch.Generator(device=dev).manual_seed(3)
+    ids = torch.randint(0, cfg.vocab, (B, S + new), generator=g, device=dev)
+    x = ops.embedding(eng.embed, ids.reshape(-1).contiguous()).view(B, S + new, hidden)
+    ref_all = eng.prefill(x, *eng.alloc_cache(B, S + new), all_logits=True)[1].float()      # [B, S+new, vocab]: teacher-forced logits
+
+    def run(fused, device_pos):
+        os.environ["AVLLM_DECODE_FUSED"] = "1" if fused else "0"
+        try:
+            kc, vc = eng.alloc_cache(B, S + new + 2)
+            eng.prefill(x[:, :S].contiguous(), kc, vc)
+            pd = torch.zeros(1, device=dev, dtype=torch.int32) if device_pos else None
+            outs = []
+            for t in range(new):
+                if device_pos:
+                    outs.append(eng.decode_step(ids[:, S + t].contiguous(), S, kc, vc, pos_dev=pd).clone())
+                    ops.L.check(ops.L.load().avllm_pos_advance(ops.L.ptr(pd), 1, ops.L.stream_ptr()))
+                else:
+                    outs.append(eng.decode_step(ids[:, S + t].contiguous(), S + t, kc, vc).clone())
+            return torch.stack(outs, 1)
+        finally:
+            os.environ.pop("AVLLM_DECODE_FUSED", None)
+
+    general, fused, fused_dev = run(False, False), run(True, False), run(True, True)
+    want = ref_all[:, S:S + new]
+    assert rel_l2(general, want) < BF16_LOGITS_REL_L2
+    assert rel_l2(fused, want) < BF16_LOGITS_REL_L2
+    assert rel_l2(fused, general) < BF16_LOGITS_REL_L2
+    assert torch.equal(fused, fused_dev)                          # same kernels, the position merely comes from memory
+    with pytest.raises(ValueError):
+        os.environ["AVLLM_DECODE_FUSED"] = "0"
+        try:
+            eng.decode_step(ids[:, 0].contiguous(), 1, *eng.alloc_cache(B, 4), pos_dev=torch.zeros(1, device=dev, dtype=torch.int32))
+        finally:
+            os.environ.pop("AVLLM_DECODE_FUSED", None)

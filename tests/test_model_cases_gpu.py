@@ -206,10 +206,10 @@ def test_deep_connector_matches_reference_fixture(dev, golden_dir):
     for tag, name in (("a", "deep"), ("b", "perceiver")):
         layers = int(g[tag + ".layers"])
         for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 6e-2)):
-            c = create_modality_connector(name, 48, 96, device=dev, dtype=dtype, num_layers=layers)
+            c = create_modality_connector(name, 64, 128, device=dev, dtype=dtype, num_layers=layers)
             assert isinstance(c, DeepModalityConnector)
             c.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")})
             y = c(torch.from_numpy(g[tag + ".x"]).to(dev)).float().cpu()
-            assert y.shape == (2, 9, 96) and (y - torch.from_numpy(g[tag + ".y"])).abs().max() < tol
+            assert y.shape == (2, 9, 128) and (y - torch.from_numpy(g[tag + ".y"])).abs().max() < tol
     with pytest.raises(NotImplementedError):
-        create_modality_connector("conv", 48, 96, device=dev)
+        create_modality_connector("conv", 64, 128, device=dev)
