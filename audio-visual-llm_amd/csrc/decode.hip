@@ -68,10 +68,32 @@ template <int OFF> __device__ __forceinline__ void gld_nt(frag& r, const bf16* p
 template <int N> __device__ __forceinline__ void wait_vm(frag& a, frag& b, frag& c) {
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
 }
+template <int N> __device__ __forceinline__ void wait_vm(frag& a, frag& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
-struct DecGrp { frag wb[4], xa[4], gw[4]; };      // 4 K-steps of 32: weight rows, activation rows, norm weights
+// DPP moves inside each row of 16 lanes (the fr index of an MFMA operand): rotate so that lane i reads lane i + S, or broadcast lane J
+template <int CTRL> __device__ __forceinline__ frag dpp4(frag v) {
+    frag r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_update_dpp((int)v[e], (int)v[e], CTRL, 0xf, 0xf, false);
+    return r;
+}
+template <int S> __device__ __forceinline__ frag row_from_higher(frag v) { return dpp4<0x120 + ((16 - S) & 15)>(v); }      // row_ror:(16 - S)
+template <int J> __device__ __forceinline__ frag row_bcast(frag v) { return dpp4<0x150 + J>(v); }                           // row_newbcast:J
 
-template <bool NORM, int VAR>
+// One ring group = 4 K-steps of 32.  The weight stream is NOT what limits a projection: a pure read of the same bytes in the same pattern
+// runs at 5.6 TB/s, adding one activation load per weight load drops it to 4.0 (tools/ubench/stream_features.hip): the CU's vector-memory
+// path is the limiter, so every load that is not a weight load has to go.  AL = activation loads per group:
+//   M > 8: 4 (lane (fr, fq) = row fr of one step);  M <= 8: 2 (lanes fr >= 8 fetch rows 0..7 of the NEXT step and a row rotate brings them
+//   down when that step is consumed; MFMA output columns >= 8 are garbage nobody reads);  M <= 4: 1 (four steps per load).
+// The norm weights of the 4 steps come in ONE load (lane row fr & 3 holds step fr & 3) and reach all rows through a row broadcast.
+template <int AL, bool NORM> struct DecGrp { frag wb[4], xa[AL], gw; };
+
+template <bool NORM, int AL>
 __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
     __shared__ float part[DW][16][17];      // [wave][n][m]
     __shared__ float ssq[DW][16];
@@ -79,31 +101,43 @@ __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int M = a.M;
-    const int ar = fr < M ? fr : M - 1;
+    constexpr int SPL = 4 / AL;              // K-steps per activation load
+    constexpr int RPL = 16 / SPL;            // activation rows per load
+    const int arow = fr & (RPL - 1), asub = fr / RPL;
+    const int ar = arow < M ? arow : M - 1;
     // K in units of 4 steps (128 columns), dealt to the 8 waves as evenly as whole units allow (K = 11008: 11,11,11,11,11,11,10,10)
     const int U = a.K >> 7, ub = U / DW, ue = U - ub * DW;
     const int G = ub + (w < ue ? 1 : 0);
     const long k0 = ((long)w * ub + (w < ue ? w : ue)) << 7;
     int col;
     const int wr = dec_wrow(a, blockIdx.x, fr, col);
-    const bf16* ap = a.A + (long)ar * a.lda + k0 + fq * 8;
+    const bf16* ap = a.A + (long)ar * a.lda + k0 + asub * 32 + fq * 8;
     const bf16* bp = a.W + (long)wr * a.ldw + k0 + fq * 8;
-    const bf16* gp = NORM ? a.norm_w + k0 + fq * 8 : a.A;
+    const bf16* gp = NORM ? a.norm_w + k0 + (fr & 3) * 32 + fq * 8 : a.A;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
-    constexpr int L = NORM ? 3 : 2;          // loads per K-step
-    DecGrp ga, gb;
-    auto issue1 = [&](DecGrp& g, auto jc, int grp) {
-        constexpr int j = decltype(jc)::value;
-        if (VAR == 1) gld<64 * j>(g.wb[j], bp + (long)grp * 128);
-        else gld_nt<64 * j>(g.wb[j], bp + (long)grp * 128);
-        gld<64 * j>(g.xa[j], ap + (long)grp * 128);
-        if (NORM) gld<64 * j>(g.gw[j], gp + (long)grp * 128);
+    constexpr int LG = 4 + AL + (NORM ? 1 : 0);          // loads per group, issued as: [norm] then per step: [activation if the step starts a load] weight
+    typedef DecGrp<AL, NORM> Grp;
+    Grp ga, gb;
+    auto issue = [&](Grp& g, int grp) {
+        if constexpr (NORM) gld<0>(g.gw, gp + (long)grp * 128);
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j % SPL == 0) gld<64 * j>(g.xa[j / SPL], ap + (long)grp * 128);
+            gld_nt<64 * j>(g.wb[j], bp + (long)grp * 128);
+        });
     };
-    auto mma = [&](DecGrp& g, int j) {
-        bf16x8 x = __builtin_bit_cast(bf16x8, g.xa[j]);
-        if (NORM) {
-            const bf16x8 gv = __builtin_bit_cast(bf16x8, g.gw[j]);
+    auto step = [&](Grp& g, auto jc, auto behind) {      // wait for step j of this group (`behind` younger groups in flight), multiply
+        constexpr int j = decltype(jc)::value;
+        constexpr int through = (NORM ? 1 : 0) + (j / SPL + 1) + (j + 1);            // loads of this group issued up to and including weight j
+        constexpr int N = LG - through + decltype(behind)::value * LG;
+        if constexpr (NORM) wait_vm<N>(g.wb[j], g.xa[j / SPL], g.gw);
+        else wait_vm<N>(g.wb[j], g.xa[j / SPL]);
+        frag xr = g.xa[j / SPL];
+        if constexpr (j % SPL != 0) xr = row_from_higher<RPL * (j % SPL)>(xr);
+        bf16x8 x = __builtin_bit_cast(bf16x8, xr);
+        if constexpr (NORM) {
+            const bf16x8 gv = __builtin_bit_cast(bf16x8, row_bcast<j>(g.gw));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xf = (float)x[e];
@@ -113,53 +147,28 @@ __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
         }
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, g.wb[j]), x, acc, 0, 0, 0);      // D[n][m]
     };
-    // steady state: 7 younger steps stay in flight behind the one consumed; its slot is refilled with the same step of group `nxt`
-    auto steady = [&](DecGrp& g, int nxt) {
-        if (VAR == 2) {          // refill in pairs: the two 64-byte halves of every 128-byte line are requested back to back
-            wait_vm<7 * L>(g.wb[0], g.xa[0], g.gw[0]); mma(g, 0);
-            wait_vm<6 * L>(g.wb[1], g.xa[1], g.gw[1]); mma(g, 1);
-            issue1(g, std::integral_constant<int, 0>{}, nxt); issue1(g, std::integral_constant<int, 1>{}, nxt);
-            wait_vm<7 * L>(g.wb[2], g.xa[2], g.gw[2]); mma(g, 2);
-            wait_vm<6 * L>(g.wb[3], g.xa[3], g.gw[3]); mma(g, 3);
-            issue1(g, std::integral_constant<int, 2>{}, nxt); issue1(g, std::integral_constant<int, 3>{}, nxt);
-            return;
-        }
-        wait_vm<7 * L>(g.wb[0], g.xa[0], g.gw[0]); mma(g, 0); issue1(g, std::integral_constant<int, 0>{}, nxt);
-        wait_vm<7 * L>(g.wb[1], g.xa[1], g.gw[1]); mma(g, 1); issue1(g, std::integral_constant<int, 1>{}, nxt);
-        wait_vm<7 * L>(g.wb[2], g.xa[2], g.gw[2]); mma(g, 2); issue1(g, std::integral_constant<int, 2>{}, nxt);
-        wait_vm<7 * L>(g.wb[3], g.xa[3], g.gw[3]); mma(g, 3); issue1(g, std::integral_constant<int, 3>{}, nxt);
-    };
-    auto drain = [&](DecGrp& g, auto behind) {          // no refill: `behind` younger groups (0 or 1) are still in flight
-        constexpr int Y = decltype(behind)::value * 4 * L;
-        wait_vm<Y + 3 * L>(g.wb[0], g.xa[0], g.gw[0]); mma(g, 0);
-        wait_vm<Y + 2 * L>(g.wb[1], g.xa[1], g.gw[1]); mma(g, 1);
-        wait_vm<Y + 1 * L>(g.wb[2], g.xa[2], g.gw[2]); mma(g, 2);
-        wait_vm<Y>(g.wb[3], g.xa[3], g.gw[3]); mma(g, 3);
-    };
-    auto issue = [&](DecGrp& g, int grp) {
-        issue1(g, std::integral_constant<int, 0>{}, grp); issue1(g, std::integral_constant<int, 1>{}, grp);
-        issue1(g, std::integral_constant<int, 2>{}, grp); issue1(g, std::integral_constant<int, 3>{}, grp);
-    };
+    auto consume = [&](Grp& g, auto behind) { static_for<0, 4>([&](auto jc) { step(g, jc, behind); }); };
     const std::integral_constant<int, 0> none{};
     const std::integral_constant<int, 1> one{};
-    // Single-exit loops with fixed slot roles (a loop whose exit alternates between the two groups makes the compiler copy ring registers
-    // that still have loads in flight): an odd group count peels one refill first, which swaps the roles for the rest of the wave's life.
+    // Two groups in flight; a group is refilled in one burst once its 4 steps are consumed.  Single-exit loops with fixed slot roles (a loop
+    // whose exit alternates between the groups makes the compiler copy ring registers that still have loads in flight): an odd group count
+    // peels one refill first, which swaps the roles for the rest of the wave's life.
     if (G == 1) {
         issue(ga, 0);
-        drain(ga, none);
+        consume(ga, none);
     } else if (G >= 2 && !(G & 1)) {
         issue(ga, 0);
         issue(gb, 1);
-        for (int g = 0; g + 2 < G; g += 2) { steady(ga, g + 2); steady(gb, g + 3); }
-        drain(ga, one);
-        drain(gb, none);
+        for (int g = 0; g + 2 < G; g += 2) { consume(ga, one); issue(ga, g + 2); consume(gb, one); issue(gb, g + 3); }
+        consume(ga, one);
+        consume(gb, none);
     } else if (G >= 3) {
         issue(ga, 0);
         issue(gb, 1);
-        steady(ga, 2);
-        for (int g = 1; g + 2 < G; g += 2) { steady(gb, g + 2); steady(ga, g + 3); }
-        drain(gb, one);
-        drain(ga, none);
+        consume(ga, one); issue(ga, 2);
+        for (int g = 1; g + 2 < G; g += 2) { consume(gb, one); issue(gb, g + 2); consume(ga, one); issue(ga, g + 3); }
+        consume(gb, one);
+        consume(ga, none);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) part[w][fq * 4 + i][fr] = acc[i];
@@ -311,11 +320,11 @@ bool av_dec_proj_supported(int dtype, int M, int K, int N, int mode, int hd) {
 
 static int dec_launch(DecArgs& a, hipStream_t st) {
     const int grid = a.mode == DEC_SWIGLU ? a.N / 8 : a.N / 16;
-    const char* ev = getenv("AVLLM_DEC_VARIANT");
-    const int var = ev ? atoi(ev) : 0;
-#define DEC_LAUNCH(NORMV, VARV) hipLaunchKernelGGL((dec_proj_kernel<NORMV, VARV>), dim3(grid), dim3(DW * 64), 0, st, a)
-    if (a.norm_w) { if (var == 1) DEC_LAUNCH(true, 1); else if (var == 2) DEC_LAUNCH(true, 2); else DEC_LAUNCH(true, 0); }
-    else { if (var == 1) DEC_LAUNCH(false, 1); else if (var == 2) DEC_LAUNCH(false, 2); else DEC_LAUNCH(false, 0); }
+#define DEC_LAUNCH(NORMV, ALV) hipLaunchKernelGGL((dec_proj_kernel<NORMV, ALV>), dim3(grid), dim3(DW * 64), 0, st, a)
+    const char* ev = getenv("AVLLM_DEC_AL");       // experiment knob: force the activation-load form (4 = one load per step)
+    const int al = ev ? atoi(ev) : (a.M <= 4 ? 1 : a.M <= 8 ? 2 : 4);
+    if (a.norm_w) { if (al == 1 && a.M <= 4) DEC_LAUNCH(true, 1); else if (al <= 2 && a.M <= 8) DEC_LAUNCH(true, 2); else DEC_LAUNCH(true, 4); }
+    else { if (al == 1 && a.M <= 4) DEC_LAUNCH(false, 1); else if (al <= 2 && a.M <= 8) DEC_LAUNCH(false, 2); else DEC_LAUNCH(false, 4); }
 #undef DEC_LAUNCH
     AV_LAUNCH_CHECK();
     return AV_OK;

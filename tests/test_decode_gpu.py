@@ -23,7 +23,7 @@ def rms(x, w, eps):
 # K / 128 units dealt to the 8 waves: 1 (one wave works), 3, 9 (two groups on one wave), 23 (odd / even group counts mixed: 3,3,3,3,3,3,3,2),
 # 32 (4096: four groups each), 86 (11008: 11 / 10)
 @pytest.mark.parametrize("K", [128, 384, 1152, 2944, 4096, 11008])
-@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("M", [1, 3, 4, 5, 8, 9, 16])
 def test_dec_proj_plain_norm_residual(dev, M, K):
     N = 528
     A, W = rnd(M, K, dtype=BF, seed=1), rnd(N, K, dtype=BF, seed=2, scale=K ** -0.5)
@@ -37,6 +37,23 @@ def test_dec_proj_plain_norm_residual(dev, M, K):
     assert rel_l2(ops.dec_proj(A, W, norm_w=g, eps=1e-5, out_f32=True), refn) < 6e-3  # the normed operand is rounded to bf16 once, like the unfused path's xn
     rows = rnd(4 * M, K, dtype=BF, seed=5)                                           # strided A rows
     assert rel_l2(ops.dec_proj(rows[3::4], W, out_f32=True), rows[3::4].float() @ W.float().t()) < 2e-3
+
+
+@pytest.mark.parametrize("M,al", [(1, "2"), (3, "4"), (4, "2"), (8, "4")])
+def test_dec_proj_activation_load_forms(dev, M, al):
+    """M <= 8 / M <= 4 share one activation load between 2 / 4 K-steps (row rotate inside the MFMA operand); AVLLM_DEC_AL forces the
+    wider forms on the same inputs: the sums are bit-identical (same products, same order)."""
+    K = 2944
+    A, W = rnd(M, K, dtype=BF, seed=1), rnd(528, K, dtype=BF, seed=2, scale=K ** -0.5)
+    g = (1.0 + 0.1 * rnd(K, dtype=torch.float32, seed=4)).to(BF)
+    want = ops.dec_proj(A, W, out_f32=True), ops.dec_proj(A, W, norm_w=g, eps=1e-5, out_f32=True)
+    os.environ["AVLLM_DEC_AL"] = al
+    try:
+        got = ops.dec_proj(A, W, out_f32=True), ops.dec_proj(A, W, norm_w=g, eps=1e-5, out_f32=True)
+    finally:
+        os.environ.pop("AVLLM_DEC_AL", None)
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    assert rel_l2(want[1], rms(A, g, 1e-5) @ W.float().t()) < 6e-3
 
 
 @pytest.mark.parametrize("M,K,F", [(1, 256, 64), (8, 4096, 11008), (16, 1152, 520)])
