@@ -875,7 +875,56 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
                                             cp0 + (i * 16) * ldc + 32 * p);
             }
         };
-        if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
+        // Residual without activation on a full tile (out-projection, fc2, o, down, gradient sums): the residual rows are fetched ONE ROW BLOCK
+        // AHEAD of the stores.  In `run` a residual load sits behind the previous chunk's store, which may alias it (in-place residual), so it
+        // cannot be hoisted and every chunk pays load -> vmcnt(0) -> store: clip out-projection 442 us without residual, 650 us with.
+        // The loads are inline asm with explicit vmcnt waits (VMEM operations of a wave complete in issue order): compiler-visible loads
+        // consumed later leave the wait-count pass with "pending" state at the joins, which reaches the K loop as a vmcnt(0) per K-step
+        // (measured: every GEMM 10 % slower).  Extra compiler-made VMEM operations (spill reloads) between them only make a wait longer.
+        auto run_res = [&]() __attribute__((always_inline)) {
+            // residual row blocks in flight ahead of the one being stored.  2 or 3 cost 28 spilled registers whose scratch reloads put
+            // compiler-made waits (vmcnt(14) .. vmcnt(6)) into the K loop: llama o-projection 108 -> 138 us (tests/test_codegen_cpu.py guards this)
+            constexpr int RD = 1;
+            u32x4 rr[RD + 1][4];
+            auto fetch = [&](int i) __attribute__((always_inline)) {
+                const bf16* rp = rp0 + (long)(i * 16) * ldr;
+                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                             : "=&v"(rr[i % (RD + 1)][0]), "=&v"(rr[i % (RD + 1)][1]), "=&v"(rr[i % (RD + 1)][2]), "=&v"(rr[i % (RD + 1)][3]) : "v"(rp) : "memory");
+            };
+#pragma clang loop unroll(full)
+            for (int i = 0; i < RD; ++i) fetch(i);
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 8; ++i) {
+                if (i + RD < 8) fetch(i + RD);
+                // younger operations behind a load of row i at its wait: 3 of its own row / earlier stores of the row, 4 per later row in
+                // flight, 4 per row stored since the load was issued
+                const int nw = 3 + 4 * (RD < 7 - i ? RD : 7 - i) + 4 * (RD < i ? RD : i);
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 4; ++p) {
+                    u32x4& x = rr[i % (RD + 1)][p];
+                    if (nw == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(x) :: "memory");
+                    else if (nw == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(x) :: "memory");
+                    else if (nw == 15) asm volatile("s_waitcnt vmcnt(15)" : "+v"(x) :: "memory");
+                    else if (nw == 19) asm volatile("s_waitcnt vmcnt(19)" : "+v"(x) :: "memory");
+                    else if (nw == 23) asm volatile("s_waitcnt vmcnt(23)" : "+v"(x) :: "memory");
+                    else if (nw == 27) asm volatile("s_waitcnt vmcnt(27)" : "+v"(x) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(x) :: "memory");
+                    const bf16x8 r = __builtin_bit_cast(bf16x8, x);
+                    const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (g.e.bias != nullptr) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] += b[p][c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] += (float)r[c];
+                    store_f<8>(cp0 + (i * 16) * ldc + 32 * p, v);
+                }
+            }
+        };
+        if (stores_in_flight && g.e.R && g.e.act == AV_ACT_NONE) run_res();       // stores_in_flight == full tile (and no debug knobs)
+        else if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
         else if (g.e.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
         else if (g.e.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
         else run(std::integral_constant<int, AV_ACT_SILU>{});

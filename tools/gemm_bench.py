@@ -19,19 +19,22 @@ CALIBRATE = os.environ.get("CALIBRATE", "0") == "1"     # also time torch.matmul
 def main():
     dev = "cuda"
     act = int(os.environ.get("ACT", "0"))
+    resid = os.environ.get("RESID", "0")                  # 1: bias + in-place residual (out-projection / fc2 / o / down as the model calls them); 2: residual from a second tensor
     for M, N, K, tag in SHAPES:
         A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         B = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * K ** -0.5
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        bias = torch.randn(N, device=dev, dtype=torch.bfloat16) if act else None
+        bias = torch.randn(N, device=dev, dtype=torch.bfloat16) if act or resid != "0" else None
+        R = out if resid == "1" else torch.zeros_like(out) if resid == "2" else None
+        out.zero_()
         for _ in range(3):
-            ops.gemm(A, B, out=out, bias=bias, act=act)
+            ops.gemm(A, B, out=out, bias=bias, act=act, R=R)
         torch.cuda.synchronize()
         n = 20 if M < 100000 else 8
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
-            ops.gemm(A, B, out=out, bias=bias, act=act)
+            ops.gemm(A, B, out=out, bias=bias, act=act, R=R)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         extra = ""
