@@ -26,10 +26,7 @@ class SimpleModalityConnector(nn.Module):
             x = ops.cast(x, self.dtype)
         shp = x.shape
         if x.dim() == 3 and not x.is_contiguous():
-            out = torch.empty(shp[0], shp[1], self.output_dim, device=x.device, dtype=self.dtype)
-            for b in range(shp[0]):                               # row-sliced view (first L frames of each item)
-                ops.gemm(x[b], self.linear.weight, out=out[b], bias=self.linear.bias)
-            return out
+            x = x.contiguous()                                    # row-sliced view (first L frames of each item): one strided copy, then ONE projection
         y = ops.gemm(x.reshape(-1, shp[-1]), self.linear.weight, bias=self.linear.bias)
         return y.view(*shp[:-1], self.output_dim)
 

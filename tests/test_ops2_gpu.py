@@ -248,7 +248,7 @@ def test_gemm_auto_dispatch_long_k_matches_16wave(dev):
     close(auto[rows], ref, 0.05, 2e-2, "auto-dispatched long-K gemm")
 
 
-@pytest.mark.parametrize("K,K2,act", [(128, 0, "none"), (64, 64, "none"), (192, 64, "quick_gelu"), (320, 0, "gelu")])
+@pytest.mark.parametrize("K,K2,act", [(128, 0, "none"), (64, 64, "none"), (192, 64, "quick_gelu"), (320, 0, "gelu"), (4096, 64, "quick_gelu"), (4096, 64, "none")])
 def test_gemm_persistent_kernel_many_tiles(dev, K, K2, act):
     """The persistent 4-wave kernel with more tiles than CUs (each workgroup walks several tiles, the K-step pipeline runs across tile
     boundaries, odd and even K-step counts so the buffer parity flips between tiles), ragged M / N edges, bias + in-place residual +
