@@ -147,6 +147,8 @@ _SIGS = {
     "avllm_llama_decode_step_at": ([C.POINTER(Llama), vp, i32, i32, vp, vp, vp, i32, vp, vp, sz, vp], i32),
     "avllm_pos_advance": ([vp, i32, vp], i32),
     "avllm_dec_proj": ([C.POINTER(DecProjDesc), vp], i32),
+    "avllm_lora_rank3": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp], i32),
+    "avllm_gemm_tn_multi": ([vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp], i32),
     "avllm_attention_decode": ([vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, f32, i32, i32, vp], i32),
 }
 

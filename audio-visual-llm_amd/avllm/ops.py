@@ -219,6 +219,34 @@ def lora_dx_masked(Ts, ATs, seeds, r, p, R=None, out=None, seed_dev=None):
     return out
 
 
+def lora_rank3(As, Bs, outs, r, alpha=1.0, seeds=None, p=0.0, shared=False, seed_dev=None):
+    """Batched rank-side products of up to 3 adapters (avllm_lora_rank3): outs[j][M,64] = alpha * A_j . Bs[j][r,K]^T (columns >= 16 zero).
+    shared=True: every adapter reads As[0] through its own dropout mask (seeds[j], p)."""
+    n = len(Bs)
+    arr = lambda ty, vals: (ty * n)(*vals)
+    Aa = [As[0]] * n if shared else As
+    L.check(L.load().avllm_lora_rank3(arr(L.vp, [L.ptr(t) for t in Aa]), arr(L.i64, [_ld(t) for t in Aa]), arr(L.i32, [t.shape[1] for t in Aa]),
+                                      arr(L.vp, [L.ptr(t) for t in Bs]), arr(L.i64, [_ld(t) for t in Bs]), arr(L.vp, [L.ptr(t) for t in outs]),
+                                      arr(L.i64, [_ld(t) for t in outs]), arr(C.c_uint32, [(s & 0xFFFFFFFF) for s in (seeds or [0] * n)]), n,
+                                      Aa[0].shape[0], r, alpha, p, seed_dev, int(shared), L.dt_of(Aa[0]), L.stream_ptr()))
+    return outs
+
+
+def gemm_tn_multi(big, smalls, outs, r, alpha=1.0, seeds=None, p=0.0, shared=False, cols=None, seed_dev=None):
+    """Batched LoRA-gradient reductions over tokens (avllm_gemm_tn_multi), ACCUMULATING into the fp32 outs.
+    shared=True: outs[j][r, NB] += alpha * smalls[j]^T . dropout_j(big); shared=False: outs[j][ncol_j, r] += alpha * big[:, cols[j]]^T . smalls[j]
+    with cols = [(col0, ncol), ...] tiling big's columns."""
+    n = len(smalls)
+    arr = lambda ty, vals: (ty * n)(*vals)
+    c0 = arr(L.i32, [c[0] for c in cols]) if cols else None
+    nc = arr(L.i32, [c[1] for c in cols]) if cols else None
+    L.check(L.load().avllm_gemm_tn_multi(L.ptr(big), _ld(big), big.shape[1], arr(L.vp, [L.ptr(t) for t in smalls]), arr(L.i64, [_ld(t) for t in smalls]),
+                                         arr(L.vp, [L.ptr(t) for t in outs]), arr(L.i64, [_ld(t) for t in outs]), c0, nc,
+                                         arr(C.c_uint32, [(s & 0xFFFFFFFF) for s in (seeds or [0] * n)]), n, r, big.shape[0], alpha, p, seed_dev,
+                                         int(shared), L.dt_of(big), L.stream_ptr()))
+    return outs
+
+
 def mx_quantize(x, layout=0):
     """x [R,K] bf16/f32 -> (q uint8 [R,K] e4m3, scale image uint8 tensor): OCP-MX block scaling, 32 elements per E8M0 scale.
     layout 0 = activation side, 1 = weight side of avllm_gemm_f8."""

@@ -47,6 +47,12 @@ int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st, int G = 1);
 int av_attention_decode1(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd, int Tk, const int* tk_dev,
                          int Tmax, float scale, int dtype, hipStream_t st, int G);
+bool av_lora_batch_supported(int dtype, int R, int nj);
+int av_lora_rank3(const void* const* A, const long* lda, const int* K, const void* const* B, const long* ldb, void* const* C, const long* ldc,
+                  const uint32_t* seeds, int nj, int M, int R, float alpha, float p, const uint32_t* seed_dev, int shared, int dtype, hipStream_t st);
+int av_gemm_tn_multi(const void* Big, long ldb, int NB, const void* const* Small, const long* lds, float* const* out, const long* ldo,
+                     const int* col0, const int* ncol, const uint32_t* seeds, int nj, int R, int M, float alpha, float p,
+                     const uint32_t* seed_dev, int shared, int dtype, hipStream_t st);
 bool av_dec_proj_supported(int dtype, int M, int K, int N, int mode, int hd);
 int av_dec_proj(const avllm_dec_proj_desc* d, hipStream_t st);
 int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev = nullptr);

@@ -363,10 +363,27 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
             AV_TRY(f8_quant(w.f8, a.xn1, d, M, d, st));
             AV_TRY(f8_proj(w.f8, M, d, P.wqkv8, P.sqkv8, qw, a.qkv, qw, nullptr, AV_ACT_NONE, nullptr, 0, st));
         }
+        // all three rank-side products t_j = s * dropout_j(xn1) A_j^T in one launch (xn1 read once): csrc/lora_batch.hip
+        const bool batch_qkv = !fp8 && dt == AV_BF16 && P.lora[0].A_pad && P.lora[1].A_pad && P.lora[2].A_pad && (!drop || fuse_drop) &&
+                               d % 256 == 0 && av_lora_batch_supported(dt, m->lora_r, 3) && !getenv("AVLLM_LORA_UNBATCHED");
+        if (batch_qkv) {
+            const void* Ap[3] = {a.xn1, a.xn1, a.xn1}; const long la[3] = {d, d, d}; const int Kk[3] = {d, d, d};
+            const void* Bp[3] = {P.lora[0].A_pad, P.lora[1].A_pad, P.lora[2].A_pad}; const long lb[3] = {d, d, d};
+            void* Cp[3]; long lc[3]; uint32_t sd[3];
+            for (int j = 0; j < 3; ++j) { Cp[j] = (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es; lc[j] = 3 * AVLLM_LORA_PAD; sd[j] = m->dropout_seed + 4u * l + j; }
+            AV_TRY(av_lora_rank3(Ap, la, Kk, Bp, lb, Cp, lc, sd, 3, M, m->lora_r, m->lora_scale, drop ? m->lora_dropout : 0.f, m->dropout_seed_dev, 1, dt, st));
+        }
         for (int j = 0; j < 3; ++j) {
             const void* xl = nullptr;
             const uint32_t sj = m->dropout_seed + 4u * l + j;
             if (drop && !fuse_drop && P.lora[j].A_pad) { AV_TRY(av_dropout(a.xn1, w.xd, M, d, sj, m->lora_dropout, dt, st, m->dropout_seed_dev)); xl = w.xd; }
+            if (batch_qkv) {      // the projection with the adapter term as its second K segment; t_j is already there
+                avllm_gemm_desc gp = gemm_desc(dt, a.xn1, d, (const char*)P.wqkv + (size_t)llama_off(m, j) * d * es, d,
+                                               (char*)a.qkv + (size_t)llama_off(m, j) * es, qw, M, llama_wid(m, j), d);
+                gp.A2 = (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es; gp.lda2 = 3 * AVLLM_LORA_PAD; gp.B2 = P.lora[j].B_pad; gp.ldb2 = AVLLM_LORA_PAD; gp.K2 = AVLLM_LORA_PAD;
+                AV_TRY(av_gemm(&gp, st));
+                continue;
+            }
             if (fp8) {
                 AV_TRY(lora_add(m, a.xn1, d, d, llama_wid(m, j), P.lora[j], (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es, 3 * AVLLM_LORA_PAD,
                                 (char*)a.qkv + (size_t)llama_off(m, j) * es, qw, M, st, xl, sj, fuse_drop ? m->lora_dropout : 0.f));
@@ -503,6 +520,28 @@ extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* 
         if (!fuse_rope) AV_TRY(av_rope_tab(dqkv, qw, M, S, H + Hkv, hd, w.rope_tab, 1, dt, st));
         // ---- q,k,v projections (+LoRA)
         bool any = false, contiguous = true;
+        const bool batch_bwd = dt == AV_BF16 && P.lora[0].A_pad && P.lora[1].A_pad && P.lora[2].A_pad && (!drop || fuse_drop) && d % 256 == 0 &&
+                               dkv % 256 == 0 && av_lora_batch_supported(dt, R, 3) && !getenv("AVLLM_LORA_UNBATCHED");
+        if (batch_bwd) {      // three launches for the three adapters' dB, dt and dA (csrc/lora_batch.hip) instead of nine
+            any = true;
+            const void* Tq[3]; long ltq[3]; float* gBp[3]; long lgb[3]; int c0[3], nc[3];
+            const void* dyp[3]; long ldy[3]; int Kd[3]; const void* BTp[3]; long lbt[3]; void* dtp[3]; long ldt3[3];
+            const void* dtc[3]; float* gAp[3]; long lga[3]; uint32_t sd[3];
+            for (int j = 0; j < 3; ++j) {
+                const avllm_lora_mod& lj = P.lora[j];
+                Tq[j] = (char*)a.tqkv + (size_t)j * AVLLM_LORA_PAD * es; ltq[j] = 3 * AVLLM_LORA_PAD; gBp[j] = lj.gB; lgb[j] = R;
+                c0[j] = llama_off(m, j); nc[j] = llama_wid(m, j);
+                dyp[j] = dqkv + (size_t)llama_off(m, j) * es; ldy[j] = qw; Kd[j] = llama_wid(m, j); BTp[j] = lj.BT_pad; lbt[j] = llama_wid(m, j);
+                dtp[j] = (char*)w.dtqkv + (size_t)j * AVLLM_LORA_PAD * es; ldt3[j] = 3 * AVLLM_LORA_PAD; dtc[j] = dtp[j];
+                gAp[j] = lj.gA; lga[j] = d; sd[j] = m->dropout_seed + 4u * l + j;
+                if (lj.ld_at != 3 * AVLLM_LORA_PAD ||
+                    (const char*)lj.AT_pad != (const char*)P.lora[0].AT_pad + (size_t)j * AVLLM_LORA_PAD * es) contiguous = false;
+            }
+            AV_TRY(av_gemm_tn_multi(dqkv, qw, qw, Tq, ltq, gBp, lgb, c0, nc, nullptr, 3, R, M, 1.0f, 0.f, nullptr, 0, dt, st));          // dB_j = dy_j^T t_j
+            AV_TRY(av_lora_rank3(dyp, ldy, Kd, BTp, lbt, dtp, ldt3, nullptr, 3, M, R, sc, 0.f, nullptr, 0, dt, st));                     // dt_j = s dy_j B_j
+            AV_TRY(av_gemm_tn_multi(a.xn1, d, d, dtc, ldt3, gAp, lga, nullptr, nullptr, sd, 3, R, M, 1.0f, drop ? m->lora_dropout : 0.f,   // dA_j = dt_j^T dropout_j(xn1)
+                                    m->dropout_seed_dev, 1, dt, st));
+        } else
         for (int j = 0; j < 3; ++j) {
             const avllm_lora_mod& lj = P.lora[j];
             if (!lj.A_pad) { contiguous = false; continue; }

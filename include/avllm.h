@@ -69,6 +69,20 @@ int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t 
 int avllm_gemm_tn_drop(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
                        float* out, int64_t ldo, float alpha, uint32_t drop_seed, float drop_p, int32_t dtype, void* stream);
 
+/* The q / k / v adapters of one decoder layer batched (bf16, rank <= 16, 1..3 adapters; peft lora.Linear on q_proj, k_proj, v_proj,
+ * clip_whisper_model.py:961-1005).  Rank-side products C_j[M,64] = alpha * A_j[M,K_j] B_j[R,K_j]^T (columns >= 16 written as zeros):
+ * shared != 0: every adapter reads A[0] through its own dropout mask (forward lora_A(dropout(x))); shared == 0: adapter j reads A[j]
+ * (backward dt_j = s dy_j B_j). */
+int avllm_lora_rank3(const void* const* A, const int64_t* lda, const int32_t* K, const void* const* B, const int64_t* ldb, void* const* C,
+                     const int64_t* ldc, const uint32_t* seeds, int32_t nj, int32_t M, int32_t R, float alpha, float p,
+                     const uint32_t* seed_dev, int32_t shared, int32_t dtype, void* stream);
+/* Reductions over tokens for the same adapters (fp32 atomic accumulation into out_j, as avllm_gemm_tn):
+ * shared != 0: out_j[R, NB] += alpha * Small_j^T . dropout_j(Big)            (dA_j; Big [M, NB] read once)
+ * shared == 0: out_j[ncol_j, R] += alpha * Big[:, col0_j:+ncol_j]^T . Small_j (dB_j; the ranges tile Big's NB columns in 128-column units) */
+int avllm_gemm_tn_multi(const void* Big, int64_t ldb, int32_t NB, const void* const* Small, const int64_t* lds, float* const* out,
+                        const int64_t* ldo, const int32_t* col0, const int32_t* ncol, const uint32_t* seeds, int32_t nj, int32_t R,
+                        int32_t M, float alpha, float p, const uint32_t* seed_dev, int32_t shared, int32_t dtype, void* stream);
+
 /* Input gradient of up to three LoRA adapters that share one input x, under lora_dropout, in one pass (bf16):
  *   out[M,N] = R[M,N] + sum_j keep(seeds[j] (+ *seed_dev), m*N+n, p)/(1-p) * (T_j[M,r] . A_j[r,N])
  * autograd of peft's lora_B(lora_A(dropout(x))) w.r.t. x (clip_whisper_model.py:961-1005).  T_j [M, >= 32 cols] (zeros past the rank, row
