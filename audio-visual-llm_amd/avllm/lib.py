@@ -64,7 +64,7 @@ class Llama(C.Structure):
 
 class GemmF8Desc(C.Structure):
     _fields_ = [("A", vp), ("SA", vp), ("B", vp), ("SB", vp), ("C", vp), ("bias", vp), ("R", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
-                ("ldr", i64), ("M", i32), ("N", i32), ("K", i32), ("act", i32)]
+                ("ldr", i64), ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("Cq", vp), ("SCq", vp), ("ldcq", i64)]
 
 
 class DecProjDesc(C.Structure):
@@ -147,6 +147,8 @@ _SIGS = {
     "avllm_llama_decode_step_at": ([C.POINTER(Llama), vp, i32, i32, vp, vp, vp, i32, vp, vp, sz, vp], i32),
     "avllm_pos_advance": ([vp, i32, vp], i32),
     "avllm_dec_proj": ([C.POINTER(DecProjDesc), vp], i32),
+    "avllm_gemm_f8_takes_quantised_output": ([C.POINTER(GemmF8Desc)], i32),
+    "avllm_norm_mxq": ([vp, vp, vp, vp, vp, vp, i64, vp, i64, i32, f32, vp], i32),
     "avllm_lora_rank3": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp], i32),
     "avllm_gemm_tn_multi": ([vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32, vp], i32),
     "avllm_attention_decode": ([vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, f32, i32, i32, vp], i32),

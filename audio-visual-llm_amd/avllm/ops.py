@@ -258,54 +258,40 @@ def mx_quantize(x, layout=0):
     return q, s
 
 
-def gemm_f8(Aq, As, Bq, Bs, out=None, bias=None, R=None, act=L.ACT_NONE):
-    """out[M,N] (bf16) = act(A.B^T + bias) + R on the block-scaled fp8 matrix pipe; (Aq, As) / (Bq, Bs) from mx_quantize(layout 0 / 1)."""
+def gemm_f8(Aq, As, Bq, Bs, out=None, bias=None, R=None, act=L.ACT_NONE, quantised_out=False):
+    """out[M,N] (bf16) = act(A.B^T + bias) + R on the block-scaled fp8 matrix pipe; (Aq, As) / (Bq, Bs) from mx_quantize(layout 0 / 1).
+    quantised_out=True: returns (codes uint8 [M,N], scale image) = the e4m3 block-scaled result, quantised in the epilogue (no bf16 copy)."""
     M, K = Aq.shape
     N = Bq.shape[0]
+    d = L.GemmF8Desc()
+    d.A, d.SA, d.B, d.SB, d.bias = L.ptr(Aq), L.ptr(As), L.ptr(Bq), L.ptr(Bs), L.ptr(bias)
+    d.lda, d.ldb = _ld(Aq), _ld(Bq)
+    d.M, d.N, d.K, d.act = M, N, K, act
+    if quantised_out:
+        q = torch.empty(M, N, device=Aq.device, dtype=torch.uint8)
+        sc = torch.zeros(L.load().avllm_mx_scale_bytes(M, N), device=Aq.device, dtype=torch.uint8)
+        d.Cq, d.SCq, d.ldcq = L.ptr(q), L.ptr(sc), N
+        L.check(L.load().avllm_gemm_f8(C.byref(d), L.stream_ptr()))
+        return q, sc
     if out is None:
         out = torch.empty(M, N, device=Aq.device, dtype=torch.bfloat16)
-    d = L.GemmF8Desc()
-    d.A, d.SA, d.B, d.SB, d.C, d.bias = L.ptr(Aq), L.ptr(As), L.ptr(Bq), L.ptr(Bs), L.ptr(out), L.ptr(bias)
-    d.lda, d.ldb, d.ldc = _ld(Aq), _ld(Bq), _ld(out)
+    d.C, d.ldc = L.ptr(out), _ld(out)
     if R is not None:
         d.R, d.ldr = L.ptr(R), _ld(R)
-    d.M, d.N, d.K, d.act = M, N, K, act
     L.check(L.load().avllm_gemm_f8(C.byref(d), L.stream_ptr()))
     return out
 
 
-def dec_proj(A, W, mode=0, norm_w=None, eps=1e-5, R=None, out=None, out_f32=False, rope=None, kc=None, vc=None, pos=0, pos_dev=None, dq=0, dkv=0, hd=0):
-    """One projection of a decode token step (avllm_dec_proj): A [M<=16, K] bf16, W [rows, K] bf16.
-    mode 0: out[M, rows] = rmsnorm?(A) . W^T (+ R);  mode 1: W = [gate; up], out[M, rows/2] = silu(gate) * up;
-    mode 2: W = [q; k; v]: RoPE on q, k with `rope` [hd/2, 2]; q -> out[M, dq]; k, v -> kc / vc [M, Tmax, dkv] at row pos (+ *pos_dev)."""
-    M, K = A.shape
-    d = L.DecProjDesc()
-    d.A, d.lda, d.W, d.ldw, d.M, d.K, d.mode = L.ptr(A), _ld(A), L.ptr(W), _ld(W), M, K, mode
-    if norm_w is not None:
-        d.norm_w, d.eps = L.ptr(norm_w), eps
-    N = W.shape[0] // 2 if mode == 1 else W.shape[0]
-    d.N = N
-    if out is None:
-        out = torch.empty(M, dq if mode == 2 else N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    d.C, d.ldc, d.out_f32 = L.ptr(out), _ld(out), int(out.dtype == torch.float32)
-    if R is not None:
-        d.R, d.ldr = L.ptr(R), _ld(R)
-    if mode == 2:
-        d.dq, d.dkv, d.hd, d.rope, d.kc, d.vc, d.Tmax, d.pos = dq, dkv, hd, L.ptr(rope), L.ptr(kc), L.ptr(vc), kc.shape[1], pos
-        d.pos_dev = L.ptr(pos_dev)
-    L.check(L.load().avllm_dec_proj(C.byref(d), L.stream_ptr()))
-    return out
-
-
-def attention_decode(q, kc, vc, H, Tk, tk_dev=None, scale=None):
-    """q [B, H*hd]; kc, vc [B, Tmax, Hkv*hd] -> [B, H*hd]: softmax(q.K^T * scale) V over cache rows [0, Tk (+ *tk_dev))."""
-    B, d = q.shape
-    hd = d // H
-    Hkv = kc.shape[2] // hd
-    o = torch.empty_like(q)
-    L.check(L.load().avllm_attention_decode(L.ptr(q), _ld(q), L.ptr(kc), L.ptr(vc), L.ptr(o), _ld(o), B, H, hd, Tk, L.ptr(tk_dev), kc.shape[1],
-                                            float(scale if scale is not None else hd ** -0.5), H // Hkv, L.dt_of(q), L.stream_ptr()))
-    return o
+def norm_mxq(x, w, b=None, eps=1e-5, want_y=False, want_rstd=False):
+    """LayerNorm (b given) / RMSNorm (b None) of bf16 rows, block-scaled to e4m3 in the same pass (avllm_norm_mxq):
+    -> (codes uint8 [rows, d], scale image, y bf16 | None, rstd | None)."""
+    rows, d = x.shape
+    q = torch.empty(rows, d, device=x.device, dtype=torch.uint8)
+    sc = torch.zeros(L.load().avllm_mx_scale_bytes(rows, d), device=x.device, dtype=torch.uint8)
+    y = torch.empty_like(x) if want_y else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if want_rstd else None
+    L.check(L.load().avllm_norm_mxq(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(rstd), L.ptr(q), d, L.ptr(sc), rows, d, eps, L.stream_ptr()))
+    return q, sc, y, rstd
 
 
 def step_advance(state, base_lr, total_steps, warmup_steps=0, beta1=0.9, beta2=0.95, rank=0):

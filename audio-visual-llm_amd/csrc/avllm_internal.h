@@ -47,6 +47,8 @@ int av_attention_decode(const void* q, long ldq, const void* kc, const void* vc,
                         int Tk, int Tmax, float scale, int dtype, hipStream_t st, int G = 1);
 int av_attention_decode1(const void* q, long ldq, const void* kc, const void* vc, void* o, long ldo, int B, int H, int hd, int Tk, const int* tk_dev,
                          int Tmax, float scale, int dtype, hipStream_t st, int G);
+int av_norm_mxq(const void* x, const void* w, const void* b, void* y, float* rstd_out, void* q, long ldq, void* scales, long rows, int d, float eps,
+                hipStream_t st);
 bool av_lora_batch_supported(int dtype, int R, int nj);
 int av_lora_rank3(const void* const* A, const long* lda, const int* K, const void* const* B, const long* ldb, void* const* C, const long* ldc,
                   const uint32_t* seeds, int nj, int M, int R, float alpha, float p, const uint32_t* seed_dev, int shared, int dtype, hipStream_t st);

@@ -62,10 +62,12 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
     for (int l = 0; l < layers; ++l) {
         const avllm_enc_layer& P = L[l];
         AV_CHECK_ARG(!fp8 || (P.wqkv8 && P.sqkv8 && P.wo8 && P.so8 && P.w18 && P.s18 && P.w28 && P.s28), "encoder layer %d: fp8 mode without fp8 weight images", l);
-        AV_TRY(av_layernorm(b.x, P.ln1_w, P.ln1_b, b.xn, M, d, eps, dtype, st));
+        const bool nq = fp8 && d % 128 == 0 && d <= 8192 && !getenv("AVLLM_F8_UNFUSED_QUANT");      // LayerNorm straight to e4m3 + scales (fp8.hip norm_mxq_kernel)
+        if (nq) AV_TRY(av_norm_mxq(b.x, P.ln1_w, P.ln1_b, nullptr, nullptr, b.f8.q, d, b.f8.s, M, d, eps, st));
+        else AV_TRY(av_layernorm(b.x, P.ln1_w, P.ln1_b, b.xn, M, d, eps, dtype, st));
         avllm_gemm_desc g;
         if (fp8) {
-            AV_TRY(f8_quant(b.f8, b.xn, d, (int)M, d, st));
+            if (!nq) AV_TRY(f8_quant(b.f8, b.xn, d, (int)M, d, st));
             AV_TRY(f8_proj(b.f8, (int)M, d, P.wqkv8, P.sqkv8, 3 * d, b.qkv, 3 * d, P.bqkv, AV_ACT_NONE, nullptr, 0, st));
         } else {
             g = gemm_desc(dtype, b.xn, d, P.wqkv, d, b.qkv, 3 * d, (int)M, 3 * d, d);
@@ -92,8 +94,24 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
         if (fp8) {      // the CLS-only last block above stays bf16: a handful of rows
             AV_TRY(f8_quant(b.f8, b.att, d, (int)M, d, st));
             AV_TRY(f8_proj(b.f8, (int)M, d, P.wo8, P.so8, d, b.x, d, P.bo, AV_ACT_NONE, b.x, d, st));
-            AV_TRY(av_layernorm(b.x, P.ln2_w, P.ln2_b, b.xn, M, d, eps, dtype, st));
-            AV_TRY(f8_quant(b.f8, b.xn, d, (int)M, d, st));
+            if (nq) AV_TRY(av_norm_mxq(b.x, P.ln2_w, P.ln2_b, nullptr, nullptr, b.f8.q, d, b.f8.s, M, d, eps, st));
+            else {
+                AV_TRY(av_layernorm(b.x, P.ln2_w, P.ln2_b, b.xn, M, d, eps, dtype, st));
+                AV_TRY(f8_quant(b.f8, b.xn, d, (int)M, d, st));
+            }
+            {   // fc1 with its output quantised in the epilogue (codes + scale image live in the bf16 ff buffer's memory: 1 + 1/32 of its 2 bytes
+                // per element), so fc2 reads them directly: no bf16 copy of the [M, ffn] activation, no quantiser pass over it
+                avllm_gemm_f8_desc q1 = {};
+                q1.A = b.f8.q; q1.SA = b.f8.s; q1.B = P.w18; q1.SB = P.s18; q1.bias = P.b1; q1.lda = d; q1.ldb = d; q1.M = (int)M; q1.N = ffn; q1.K = d; q1.act = act;
+                F8Buf ffq;
+                ffq.q = b.ff; ffq.s = (char*)b.ff + (((size_t)M * ffn + 255) & ~(size_t)255);
+                q1.Cq = ffq.q; q1.SCq = ffq.s; q1.ldcq = ffn;
+                if (!getenv("AVLLM_F8_UNFUSED_QUANT") && avllm_gemm_f8_takes_quantised_output(&q1) && (size_t)M * ffn + 256 + avllm_mx_scale_bytes((int)M, ffn) <= (size_t)M * ffn * es) {
+                    AV_TRY(av_gemm_f8(&q1, st));
+                    AV_TRY(f8_proj(ffq, (int)M, ffn, P.w28, P.s28, d, b.x, d, P.b2, AV_ACT_NONE, b.x, d, st));
+                    continue;
+                }
+            }
             AV_TRY(f8_proj(b.f8, (int)M, d, P.w18, P.s18, ffn, b.ff, ffn, P.b1, act, nullptr, 0, st));
             AV_TRY(f8_quant(b.f8, b.ff, ffn, (int)M, ffn, st));
             AV_TRY(f8_proj(b.f8, (int)M, ffn, P.w28, P.s28, d, b.x, d, P.b2, AV_ACT_NONE, b.x, d, st));

@@ -199,13 +199,15 @@ void av_prof_after(hipStream_t st, double flops);
 int av_gemm_f8_fast(const avllm_gemm_f8_desc* d, hipStream_t st, bool* taken);
 
 int av_gemm_f8(const avllm_gemm_f8_desc* d, hipStream_t st) {
-    AV_CHECK_ARG(d && d->A && d->B && d->SA && d->SB && d->C, "gemm_f8: null operand");
+    AV_CHECK_ARG(d && d->A && d->B && d->SA && d->SB && (d->C || d->Cq), "gemm_f8: null operand");
     AV_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 128 == 0, "gemm_f8: bad shape M=%d N=%d K=%d (K %% 128)", d->M, d->N, d->K);
     AV_CHECK_ARG(d->lda % 16 == 0 && d->ldb % 16 == 0 && d->ldc % 8 == 0 && (!d->R || d->ldr % 8 == 0), "gemm_f8: leading dims must keep 16-byte rows");
     const bool prof = av_prof_enabled();
     if (prof) av_prof_before(st);
     bool taken = false;
     AV_TRY(av_gemm_f8_fast(d, st, &taken));
+    if (!taken && d->Cq)
+        return av_set_error(AV_ERR_UNSUPPORTED, "gemm_f8: quantised output needs the persistent kernel (M > 128, >= 64 tiles, K >= 256, N %% 32 == 0, no residual)");
     if (!taken) {
         GemmF8Args g;
         g.A = (const uint8_t*)d->A; g.B = (const uint8_t*)d->B; g.SA = (const uint32_t*)d->SA; g.SB = (const uint32_t*)d->SB;
@@ -223,3 +225,118 @@ extern "C" int avllm_mx_quantize(const void* x, int64_t ldx, int32_t R, int32_t 
     return av_mx_quantize(x, ldx, R, K, q, ldq, scales, layout, dtype, (hipStream_t)stream);
 }
 extern "C" int avllm_gemm_f8(const avllm_gemm_f8_desc* d, void* stream) { return av_gemm_f8(d, (hipStream_t)stream); }
+
+// ------------------------------------------------------------------------------------------ LayerNorm / RMSNorm -> MX e4m3 in one pass
+// The producer of most fp8 projection inputs is a normalisation; writing it as bf16 and re-reading it in mx_quant_kernel is 4 bytes of HBM
+// traffic per element for a 1-byte result.  One wave normalises a row from registers (bf16 in, fp32 statistics as norm.hip) and block-scales
+// the fp32 result directly; a workgroup owns the 64 rows of one scale-image row group so that it can emit whole scale words.
+namespace {
+constexpr int NQ_MAXJ = 16;      // 16-byte chunks per lane: rows up to 64 * 8 * 16 = 8192 elements
+
+template <bool RMS, int NQ_J>
+__global__ __launch_bounds__(256) void norm_mxq_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, const bf16* __restrict__ b,
+                                                       bf16* __restrict__ y, float* __restrict__ rstd_out, uint8_t* __restrict__ q, long ldq,
+                                                       uint32_t* __restrict__ simg, int RB, long rows, int d, float eps) {
+    __shared__ uint8_t sb[256][64];                       // [K block][row of the group]: E8M0 bytes (d <= 8192)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rb = blockIdx.x, nkb = d >> 5, nch = d >> 3;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int rloc = 16 * wv + rr;                    // layout 0: byte i' = wave, fr' = rr
+        const long row = (long)rb * 64 + rloc;
+        if (row >= rows) {                                // wave-uniform
+            for (int kb = lane; kb < nkb; kb += 64) sb[kb][rloc] = 0;
+            continue;
+        }
+        const bf16* xr = x + row * d;
+        float v[NQ_J][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ_J; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                load_f<8>(xr + c * 8, v[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[j][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+            }
+        }
+        const float mean = RMS ? 0.f : wave_sum(s) / d;
+        float qs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ_J; ++j)
+            if (lane + 64 * j < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float u = v[j][e] - mean; qs += u * u; }
+            }
+        const float rstd = rsqrtf(wave_sum(qs) / d + eps);
+        if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+        for (int j = 0; j < NQ_J; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {                                // d % 32 == 0: the 4 lanes of a 32-element block are in or out together
+                float wv8[8], o[8];
+                load_f<8>(w + c * 8, wv8);
+                if (RMS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = wv8[e] * (v[j][e] * rstd);
+                } else {
+                    float bv8[8];
+                    load_f<8>(b + c * 8, bv8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * wv8[e] + bv8[e];
+                }
+                if (y) store_f<8>(y + row * d + c * 8, o);
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(o[e]));
+                amax = fmaxf(amax, __shfl_xor(amax, 1));
+                amax = fmaxf(amax, __shfl_xor(amax, 2));
+                int ex = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+                ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+                const float invs = __uint_as_float((uint32_t)(127 - ex) << 23);
+                float a8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = fminf(fmaxf(o[e] * invs, -448.f), 448.f);
+                int r0 = 0, r1 = 0;
+                r0 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[0], a8[1], r0, false);
+                r0 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[2], a8[3], r0, true);
+                r1 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[4], a8[5], r1, false);
+                r1 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[6], a8[7], r1, true);
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                *(u32x2*)(q + row * ldq + c * 8) = (u32x2){(uint32_t)r0, (uint32_t)r1};
+                if ((lane & 3) == 0) sb[c >> 2][rloc] = (uint8_t)(ex + 127);
+            }
+        }
+    }
+    __syncthreads();
+    // word ((t * RB + rb) * 4 + kb % 4) * 16 + fr' = bytes of rows 16 i' + fr', i' = 0..3, of K block kb = 4 t + kb % 4
+    for (int idx = threadIdx.x; idx < nkb * 16; idx += 256) {
+        const int kb = idx >> 4, fr = idx & 15;
+        const uint32_t word = (uint32_t)sb[kb][fr] | ((uint32_t)sb[kb][16 + fr] << 8) | ((uint32_t)sb[kb][32 + fr] << 16) | ((uint32_t)sb[kb][48 + fr] << 24);
+        simg[(((long)(kb >> 2) * RB + rb) * 4 + (kb & 3)) * 16 + fr] = word;
+    }
+}
+}  // namespace
+
+// y (optional bf16 copy), q / scales (layout 0) = block-scaled e4m3 of LayerNorm(x; w, b) (b != NULL) or RMSNorm(x; w) (b == NULL, rstd_out optional)
+int av_norm_mxq(const void* x, const void* w, const void* b, void* y, float* rstd_out, void* q, long ldq, void* scales, long rows, int d, float eps,
+                hipStream_t st) {
+    AV_CHECK_ARG(x && w && q && scales && rows > 0, "norm_mxq: null/empty");
+    AV_CHECK_ARG(d % 128 == 0 && d <= 64 * 8 * NQ_MAXJ && ldq >= d && ldq % 8 == 0, "norm_mxq: d=%d must be a multiple of 128 up to 8192", d);
+    const int RB = mx_groups((int)rows);
+#define NQ_LAUNCH(RMSV, J) hipLaunchKernelGGL((norm_mxq_kernel<RMSV, J>), dim3(RB), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)y, \
+                                             rstd_out, (uint8_t*)q, ldq, (uint32_t*)scales, RB, rows, d, eps)
+    const int nj = (d / 8 + 63) / 64;               // 16-byte chunks per lane
+    if (b) { if (nj <= 2) NQ_LAUNCH(false, 2); else if (nj <= 4) NQ_LAUNCH(false, 4); else if (nj <= 8) NQ_LAUNCH(false, 8); else NQ_LAUNCH(false, 16); }
+    else { if (nj <= 2) NQ_LAUNCH(true, 2); else if (nj <= 4) NQ_LAUNCH(true, 4); else if (nj <= 8) NQ_LAUNCH(true, 8); else NQ_LAUNCH(true, 16); }
+#undef NQ_LAUNCH
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+extern "C" int avllm_norm_mxq(const void* x, const void* w, const void* b, void* y, float* rstd_out, void* q, int64_t ldq, void* scales, int64_t rows,
+                              int32_t d, float eps, void* stream) {
+    return av_norm_mxq(x, w, b, y, rstd_out, q, ldq, scales, rows, d, eps, (hipStream_t)stream);
+}

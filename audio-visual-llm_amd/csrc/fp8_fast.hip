@@ -27,6 +27,7 @@
 namespace {
 
 using avg::epilogue_fast8; using avg::xcd_remap; using avg::tile_coords;
+__device__ __forceinline__ int f8_groups_dev(int R) { return (R + 255) / 256 * 4; }
 
 typedef __attribute__((ext_vector_type(8))) int v8i;
 typedef __attribute__((ext_vector_type(4))) int v4i;
@@ -40,6 +41,7 @@ struct F8Args {
     long lda, ldb;
     int K, RBA, RBB, dbg;
     void* C; long ldc; const void* bias; const void* R; long ldr; int act; int M, N;
+    uint8_t* Cq; uint32_t* SCq; long ldcq;                             // quantised output (see include/avllm.h)
 };
 
 #define F8_BOFF(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 128)
@@ -264,7 +266,67 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
                                             cp0 + (i * 16) * ldc + 32 * p);
             }
         };
-        if (g.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
+        // Quantised output: act(acc + bias) -> e4m3 + one E8M0 per 32 columns, from the fp32 values (the separate quantiser pass over a bf16
+        // copy costs a read of 2 and a write of 1 byte per element: 53 ms of a 541 ms config-5 step for the ViT-L fc1 outputs alone).
+        // A 32-column block of a row lives in the 4 lanes fq = 0..3 of one fr: amax through two cross-row shuffles.  Scale image (layout 0):
+        // word ((t * RB + rb) * 4 + blk) * 16 + fr holds the bytes of rows 64 rb + 16 i' + fr, i' = 0..3, for column block blk of K-step t of the
+        // CONSUMER (128 columns): this lane's row blocks i = 4 a + i' fill whole words; lane fq writes the words of block p == fq.
+        auto run_q = [&](auto actc) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(actc)::value;
+            uint32_t sw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            uint8_t* const qp0 = g.Cq + (long)m0 * g.ldcq + n;
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 8; ++i) {
+                const bool mrow = m0 + i * 16 < g.M;
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (g.bias != nullptr) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] += b[p][c];
+                    }
+                    if constexpr (ACT != AV_ACT_NONE) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = act_apply_fast(v[c], ACT);
+                    }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) amax = fmaxf(amax, fabsf(v[c]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;           // floor(log2 amax) - 8 (oracle/mxfp8.py, fp8.hip mx_quant_kernel)
+                    e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                    const float invs = __uint_as_float((uint32_t)(127 - e) << 23);
+                    float a8[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a8[c] = fminf(fmaxf(v[c] * invs, -448.f), 448.f);
+                    int r0 = 0, r1 = 0;
+                    r0 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[0], a8[1], r0, false);
+                    r0 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[2], a8[3], r0, true);
+                    r1 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[4], a8[5], r1, false);
+                    r1 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[6], a8[7], r1, true);
+                    if (mrow && n + 32 * p < g.N) {
+                        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                        *(u32x2*)(qp0 + (long)(i * 16) * g.ldcq + 32 * p) = (u32x2){(uint32_t)r0, (uint32_t)r1};
+                        sw[i >> 2][p] |= (uint32_t)(e + 127) << (8 * (i & 3));
+                    }
+                }
+            }
+            const int t = tn * (TN / 128) + wc, RBo = f8_groups_dev(g.M);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const uint32_t wv = fq == 0 ? sw[a][0] : fq == 1 ? sw[a][1] : fq == 2 ? sw[a][2] : sw[a][3];
+                const int rb = tm * (TM / 64) + wr * 2 + a;
+                if (tn * TN + wc * 128 + 32 * fq < g.N && rb < RBo) g.SCq[(((long)t * RBo + rb) * 4 + fq) * 16 + fr] = wv;
+            }
+        };
+        if (g.Cq) {
+            if (g.act == AV_ACT_NONE) run_q(std::integral_constant<int, AV_ACT_NONE>{});
+            else if (g.act == AV_ACT_GELU) run_q(std::integral_constant<int, AV_ACT_GELU>{});
+            else if (g.act == AV_ACT_QUICK_GELU) run_q(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
+            else run_q(std::integral_constant<int, AV_ACT_SILU>{});
+        } else if (g.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
         else if (g.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
         else if (g.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
         else run(std::integral_constant<int, AV_ACT_SILU>{});
@@ -282,17 +344,23 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
 
 }  // namespace
 
-// mx_groups() of fp8.hip
-static inline int f8_groups(int R) { return (R + 255) / 256 * 4; }
+static inline int f8_groups(int R) { return (R + 255) / 256 * 4; }      // mx_groups() of fp8.hip
+
+static bool f8_fast_takes(const avllm_gemm_f8_desc* d) {
+    static const int off = getenv("AVLLM_F8_FAST") ? atoi(getenv("AVLLM_F8_FAST")) == 0 : 0;
+    const int xtiles = av_cdiv(d->M, TM) * av_cdiv(d->N, TN);
+    const bool aligned = (d->Cq || (uintptr_t)d->C % 16 == 0) && (!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->R || (uintptr_t)d->R % 16 == 0) && d->N % 8 == 0 &&
+                         ((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0);
+    const bool fits = (double)d->M * (double)d->lda < 4.0e9 && (double)d->N * (double)d->ldb < 4.0e9 && d->lda < (1 << 24) && d->ldb < (1 << 24);
+    const bool qok = !d->Cq || (d->SCq && !d->R && d->N % 32 == 0 && d->ldcq % 8 == 0 && (uintptr_t)d->Cq % 8 == 0);
+    return !(off || d->M <= 128 || xtiles < 64 || d->K < 2 * KB || !aligned || !fits || !qok);
+}
+extern "C" int avllm_gemm_f8_takes_quantised_output(const avllm_gemm_f8_desc* d) { return d && d->Cq && f8_fast_takes(d) ? 1 : 0; }
 
 int av_gemm_f8_fast(const avllm_gemm_f8_desc* d, hipStream_t st, bool* taken) {
     *taken = false;
-    static const int off = getenv("AVLLM_F8_FAST") ? atoi(getenv("AVLLM_F8_FAST")) == 0 : 0;
+    if (!f8_fast_takes(d)) return AV_OK;
     const int xtiles = av_cdiv(d->M, TM) * av_cdiv(d->N, TN);
-    const bool aligned = ((uintptr_t)d->C % 16 == 0) && (!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->R || (uintptr_t)d->R % 16 == 0) && d->N % 8 == 0 &&
-                         ((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0);
-    const bool fits = (double)d->M * (double)d->lda < 4.0e9 && (double)d->N * (double)d->ldb < 4.0e9 && d->lda < (1 << 24) && d->ldb < (1 << 24);
-    if (off || d->M <= 128 || xtiles < 64 || d->K < 2 * KB || !aligned || !fits) return AV_OK;
     static bool attr[64] = {};
     static int ncu[64] = {};
     int dev = 0;
@@ -309,6 +377,7 @@ int av_gemm_f8_fast(const avllm_gemm_f8_desc* d, hipStream_t st, bool* taken) {
     static const int dbg_env = getenv("AVLLM_GEMM_DBG") ? atoi(getenv("AVLLM_GEMM_DBG")) : 0;
     g.dbg = dbg_env;
     g.C = d->C; g.ldc = d->ldc; g.bias = d->bias; g.R = d->R; g.ldr = d->ldr; g.act = d->act; g.M = d->M; g.N = d->N;
+    g.Cq = (uint8_t*)d->Cq; g.SCq = (uint32_t*)d->SCq; g.ldcq = d->ldcq;
     hipLaunchKernelGGL(gemm_f8_wp_kernel, dim3(xtiles < ncu[dev] ? xtiles : ncu[dev]), dim3(256), F8_LDS, st, g);
     AV_LAUNCH_CHECK();
     *taken = true;

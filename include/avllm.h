@@ -109,8 +109,20 @@ typedef struct avllm_gemm_f8_desc {
     int64_t lda, ldb, ldc, ldr;
     int32_t M, N, K;                    /* K % 128 == 0 */
     int32_t act;
+    /* Quantised output (the activation of the NEXT fp8 projection, e.g. fc1 -> fc2): when Cq != NULL the result act(A.B^T + bias) is
+     * block-scaled to e4m3 in the epilogue, straight from the fp32 accumulators -- codes uint8 [M,N] (row stride ldcq bytes) + the layout-0
+     * scale image of avllm_mx_scale_bytes(M,N) bytes in SCq -- and the bf16 C is NOT written (C may be NULL; R must be NULL; N % 32 == 0).
+     * Only the persistent kernel implements it: AVLLM_ERR_UNSUPPORTED for calls it does not take (avllm_gemm_f8_takes_quantised_output). */
+    void* Cq; void* SCq;
+    int64_t ldcq;
 } avllm_gemm_f8_desc;
+int avllm_gemm_f8_takes_quantised_output(const avllm_gemm_f8_desc* d);
 int avllm_gemm_f8(const avllm_gemm_f8_desc* d, void* stream);
+/* nn.LayerNorm (b != NULL; HF whisper / clip encoder layers) or LlamaRMSNorm (b == NULL) of bf16 rows with the result block-scaled to e4m3 in
+ * the same pass: q uint8 [rows, d] (row stride ldq) + the layout-0 scale image, ready as the A operand of avllm_gemm_f8.  y (bf16 copy of the
+ * normalised rows) and rstd_out (RMSNorm's per-row 1/rms, saved for the backward) are optional.  d % 128 == 0, d <= 8192. */
+int avllm_norm_mxq(const void* x, const void* w, const void* b, void* y, float* rstd_out, void* q, int64_t ldq, void* scales, int64_t rows,
+                   int32_t d, float eps, void* stream);
 
 /* Per-step scalars kept in DEVICE memory so that a training step is the same launch sequence every time and can be captured in a
  * hipGraph (trainer/clip_whisper_trainer.py:433-490 recomputes them on the host each step: scheduler.step() :464, the optimizer's

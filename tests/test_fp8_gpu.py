@@ -140,3 +140,94 @@ def test_model_fp8_train_step_vs_fake_quant_oracle(dev, golden_dir):
     p0 = m.llm_engine.lora_p.clone()
     losses = [float(tr.train_step(audio.to(dev), video.to(dev), labels.to(dev), prompt.to(dev))) for _ in range(3)]
     assert all(np.isfinite(losses)) and not torch.equal(p0, m.llm_engine.lora_p) and losses[-1] < losses[0] + 0.05
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 4096, 1024, "quick_gelu"), (5000, 3072, 768, "gelu"), (4100, 4096, 384, "none")])
+def test_gemm_f8_quantised_output(dev, M, N, K, act):
+    """fc1 -> fc2 without a bf16 round trip: the persistent fp8 GEMM block-scales act(A.W^T + b) to e4m3 in its epilogue.  Against the MX rule
+    (oracle/mxfp8.py) applied to the fp32 reference result: exponents equal except where the block maximum sits on a power-of-two boundary
+    within summation-order noise, codes within one e4m3 step, and the (codes, scale image) pair is accepted by the next GEMM as its A operand."""
+    from avllm import lib as L
+    from avllm import ops
+    A = rnd(M, K, dtype=torch.bfloat16, seed=21)
+    W = rnd(N, K, dtype=torch.bfloat16, seed=22, scale=K ** -0.5)
+    bias = rnd(N, dtype=torch.bfloat16, seed=23)
+    Aq, As = ops.mx_quantize(A, 0)
+    Wq, Ws = ops.mx_quantize(W, 1)
+    code = {"none": L.ACT_NONE, "gelu": L.ACT_GELU, "quick_gelu": L.ACT_QUICK_GELU}[act]
+    q, sc = ops.gemm_f8(Aq, As, Wq, Ws, bias=bias, act=code, quantised_out=True)
+    z = MX.fake_quant(A.float().cpu()) @ MX.fake_quant(W.float().cpu()).T + bias.float().cpu()
+    ref = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act](z)
+    rc, re = MX.quantize(ref)
+    e = _image_exponents(sc, 0, M, N)
+    assert float((e != re).float().mean()) < 2e-3                              # a block maximum within ~1e-6 of a power of two may land on either side
+    deq = MX.dequantize(q.cpu(), e)
+    blk = ref.abs().reshape(M, N // 32, 32).amax(-1).repeat_interleave(32, dim=1)
+    same = (e == re).repeat_interleave(32, dim=1)
+    err = (deq - ref).abs()
+    assert bool((err[same] <= blk[same] * 2.0 ** -3 + 1e-6).all())             # the quantiser's own bound (test_mx_quantizer_bit_exact)
+    assert bool((err[~same] <= blk[~same] * 2.0 ** -2).all())                  # boundary blocks: one exponent off = one more bit of step or a clamp
+    assert rel_l2(deq, MX.dequantize(rc, re)) < 5e-3                           # and the same numbers as the rule gives, up to boundary cases
+    # the pair feeds the next projection directly: equal (bf16 output) to quantising a bf16 copy first, up to the boundary cases
+    W2 = rnd(256, N, dtype=torch.bfloat16, seed=24, scale=N ** -0.5)
+    W2q, W2s = ops.mx_quantize(W2, 1)
+    direct = ops.gemm_f8(q, sc, W2q, W2s).float()
+    two_step = ops.gemm_f8(*ops.mx_quantize(ops.gemm_f8(Aq, As, Wq, Ws, bias=bias, act=code), 0), W2q, W2s).float()
+    assert rel_l2(direct, two_step) < 2e-2
+    with pytest.raises(Exception):
+        ops.gemm_f8(Aq[:64], As, Wq, Ws, quantised_out=True)                   # too small for the persistent kernel: refused, not silently slow
+
+
+@pytest.mark.parametrize("rows,d,rms", [(1000, 1024, False), (300, 1280, False), (257, 768, False), (130, 4096, True), (64, 8192, True), (5, 128, False)])
+def test_norm_mxq_one_pass(dev, rows, d, rms):
+    """LayerNorm / RMSNorm with the result block-scaled to e4m3 in the same pass (avllm_norm_mxq): against the MX rule applied to the fp32
+    normalisation of the same bf16 rows; the optional bf16 copy and 1/rms equal the plain norm kernels'."""
+    from avllm import ops
+    x = rnd(rows, d, dtype=torch.bfloat16, seed=31) * 3 + 0.5
+    w = (1 + 0.1 * rnd(d, dtype=torch.float32, seed=32)).to(torch.bfloat16)
+    b = None if rms else rnd(d, dtype=torch.bfloat16, seed=33)
+    q, sc, y, rstd = ops.norm_mxq(x, w, b, eps=1e-5, want_y=True, want_rstd=rms)
+    xf = x.float().cpu()
+    if rms:
+        r = torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-5)
+        ref = w.float().cpu() * (xf * r)
+        assert rel_l2(rstd.cpu(), r[:, 0]) < 1e-6
+        assert rel_l2(y, ops.rmsnorm_fwd(x, w, 1e-5)[0]) < 1e-3      # the same formula; the plain kernel splits a long row over 4 waves (other summation order)
+    else:
+        ref = torch.nn.functional.layer_norm(xf, (d,), w.float().cpu(), b.float().cpu(), 1e-5)
+        assert rel_l2(y, ops.layernorm(x, w, b, 1e-5)) < 1e-3
+    rc, re = MX.quantize(ref)
+    e = _image_exponents(sc, 0, rows, d)
+    assert float((e != re).float().mean()) < 2e-3
+    deq = MX.dequantize(q.cpu(), e)
+    blk = ref.abs().reshape(rows, d // 32, 32).amax(-1).repeat_interleave(32, dim=1)
+    same = (e == re).repeat_interleave(32, dim=1)
+    err = (deq - ref).abs()
+    assert bool((err[same] <= blk[same] * 2.0 ** -3 + 1e-6).all()) and bool((err[~same] <= blk[~same] * 2.0 ** -2 + 1e-6).all())
+    assert float((q.cpu() != rc).float().mean()) < 5e-3          # codes equal except where fp32 summation order moves a value across a rounding boundary
+
+
+def test_fp8_encoder_fused_quantisation_at_vit_l_width(dev, monkeypatch):
+    """ViT-L/14 width (d 1024, 16 heads, mlp 4096, 257 tokens), 2 full layers + the CLS-only last one on 48 frames (12336 rows: the persistent
+    fp8 kernel takes every projection): LayerNorm -> e4m3 in one pass and fc1's epilogue quantisation against the same engine with the separate
+    quantiser passes (AVLLM_F8_UNFUSED_QUANT=1), and both against the fake-quantised oracle."""
+    from avllm.arch import ClipCfg
+    from avllm.engine import ClipEngine
+    from bars import FP8_ENC_REL_L2
+    from oracle import avsr_oracle as O
+    from oracle import weights as Wt
+    c = Wt.ClipCfg(hidden=1024, heads=16, layers=3, mlp=4096, image=224, patch=14)
+    sd = Wt.clip_weights(c, seed=6)
+    frames = torch.randn(48, 3, 224, 224, generator=torch.Generator().manual_seed(10))
+    eng = ClipEngine(sd, ClipCfg(**vars(c)), torch.bfloat16, dev, fp8=True)
+    fused = eng.forward(frames.to(dev)).float().cpu()
+    monkeypatch.setenv("AVLLM_F8_UNFUSED_QUANT", "1")
+    unfused = eng.forward(frames.to(dev)).float().cpu()
+    monkeypatch.delenv("AVLLM_F8_UNFUSED_QUANT")
+    # they differ by the bf16 rounding the fused path skips, which flips e4m3 rounding decisions (each worth 2^-4 of the element): same class as
+    # either path's distance to the oracle
+    assert rel_l2(fused, unfused) < FP8_ENC_REL_L2, rel_l2(fused, unfused)
+    with torch.no_grad(), O.fp8_mode():
+        ref = O.clip_vision_cls(sd, c, frames[:8])
+    assert rel_l2(fused[:8], ref) < FP8_ENC_REL_L2, rel_l2(fused[:8], ref)
+    assert rel_l2(unfused[:8], ref) < FP8_ENC_REL_L2

@@ -104,7 +104,7 @@ def test_batched_and_unbatched_steps_agree(dev, monkeypatch):
         eng.pack_lora()
         out = m(audio=audio, video=video, labels=labels)
         out["loss"].backward()
-        res[mode] = (float(out["loss"]), eng.lora_g.clone())
+        res[mode] = (float(out["loss"].detach()), eng.lora_g.clone())
     assert abs(res["batched"][0] - res["unbatched"][0]) < 1e-6
     assert rel_l2(res["batched"][1], res["unbatched"][1]) < 1e-4
     assert float(res["batched"][1].abs().max()) > 0
