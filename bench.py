@@ -290,7 +290,7 @@ def main():
     dt = float(tt)
     final_loss = float(loss)
     host_leg = None
-    if not args.no_host_inputs and not args.tiny:
+    if not args.no_host_inputs and not args.tiny and world == 1:      # secondary legs run at N = 1 only: the scaling runs time the contract's step and nothing else
         host_leg = host_inputs_leg(args, cfg, model, trainer, labels, prompt, dev, rank, world, barrier)
     decode_leg = None
     if rank == 0 and world == 1 and not args.no_decode and not args.tiny:
