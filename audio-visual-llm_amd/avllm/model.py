@@ -177,6 +177,30 @@ class ClipWhisperModel:
             os.makedirs(os.path.join(output_dir, "llm"), exist_ok=True)
             torch.save({k: v for k, v in self.state_dict().items() if "lora_" in k}, os.path.join(output_dir, "llm", "adapter_model.pt"))
 
+    @classmethod
+    def from_pretrained(cls, model_dir, tokenizer=None, **kwargs):
+        """clip_whisper_model.py:821-864.  The reference's own pair is not closed: its save_pretrained writes `config.pt` / `config.json` while its
+        from_pretrained demands `model_config.json` (and `whisper/`, `clip/` directories that are only written with freeze_encoders=False), so it
+        cannot reload what it saved.  This one reloads what save_pretrained above wrote -- connectors, adapters, the saved settings -- on top of
+        base checkpoints named by the usual constructor keywords (`llm_path=`, `whisper_model=`, `clip_model=`, or `config=` + `synthetic_weights=`)."""
+        import json
+        if not os.path.exists(model_dir):
+            raise ValueError(f"Model directory {model_dir} does not exist")
+        cfg_path = os.path.join(model_dir, "config.json")
+        if not os.path.exists(cfg_path):
+            raise ValueError(f"Model config {cfg_path} does not exist")
+        cfg = json.load(open(cfg_path))
+        for k in ("modality", "max_seq_len", "fusion_scale", "use_lora", "lora_r", "lora_alpha", "connector_type"):
+            if k in cfg:
+                kwargs.setdefault(k, cfg[k])
+        model = cls(_provided_tokenizer=tokenizer, **kwargs)
+        model.audio_connector.load_state_dict(torch.load(os.path.join(model_dir, "audio_connector.pt"), map_location=model.device, weights_only=True))
+        model.video_connector.load_state_dict(torch.load(os.path.join(model_dir, "video_connector.pt"), map_location=model.device, weights_only=True))
+        adapters = os.path.join(model_dir, "llm", "adapter_model.pt")
+        if model.use_lora and os.path.exists(adapters):
+            model.load_state_dict(torch.load(adapters, map_location="cpu", weights_only=True))
+        return model
+
     def _setup_projections(self, W=None):
         """clip_whisper_model.py:1159-1190: both connectors always exist."""
         # xavier init as in the reference, but drawn from a private generator state derived from `seed` (the global RNG is left alone):

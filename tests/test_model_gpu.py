@@ -199,6 +199,33 @@ def test_state_dict_roundtrip(dev, tiny, model32, tmp_path):
             assert torch.equal(v.cpu(), sd[k].cpu()), k
 
 
+def test_save_pretrained_from_pretrained_round_trip(dev, tiny, model32, tmp_path):
+    """save_pretrained's directory (clip_whisper_model.py:738-798: audio_connector.pt, video_connector.pt, config.pt / config.json, llm/) reloads
+    through from_pretrained on top of other base weights' adapters/connectors: same eval logits afterwards.  (The reference's own from_pretrained
+    asks for model_config.json, which its save_pretrained never writes.)"""
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    g, oc, W, audio, video, labels, prompt = tiny
+    out_dir = str(tmp_path / "saved")
+    model32.save_pretrained(out_dir)
+    import os
+    for f in ("audio_connector.pt", "video_connector.pt", "config.json", "config.pt", os.path.join("llm", "adapter_model.pt")):
+        assert os.path.exists(os.path.join(out_dir, f)), f
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    W2 = dict(W)
+    W2["lora"] = {k: torch.zeros_like(v) for k, v in W["lora"].items()}                       # same frozen base, fresh adapters ...
+    W2.pop("audio_connector", None); W2.pop("video_connector", None)                          # ... and fresh connectors
+    m2 = ClipWhisperModel.from_pretrained(out_dir, device=dev, config=cfg, weights=W2, precision="fp32", lora_dropout=0.0)
+    assert m2.max_seq_len == model32.max_seq_len and m2.modality == model32.modality
+    model32.eval(); m2.eval()
+    kw = dict(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+    a, b = model32(**kw), m2(**kw)
+    assert torch.equal(a["logits"], b["logits"])
+    model32.train()
+    with pytest.raises(ValueError):
+        ClipWhisperModel.from_pretrained(str(tmp_path / "nope"))
+
+
 def test_lora_dropout_matches_oracle_with_same_masks(dev, tiny):
     """lora_dropout>0 (peft: lora_B(lora_A(dropout(x)))): the library regenerates its counter-based masks in forward and
     backward; the oracle is given the SAME masks (extracted with avllm_dropout on ones) and must agree on loss and grads."""
