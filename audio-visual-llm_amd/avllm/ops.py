@@ -294,6 +294,40 @@ def norm_mxq(x, w, b=None, eps=1e-5, want_y=False, want_rstd=False):
     return q, sc, y, rstd
 
 
+def dec_proj(A, W, mode=0, norm_w=None, eps=1e-5, R=None, out=None, out_f32=False, rope=None, kc=None, vc=None, pos=0, pos_dev=None, dq=0, dkv=0, hd=0):
+    """One projection of a decode token step (avllm_dec_proj): A [M<=16, K] bf16, W [rows, K] bf16.
+    mode 0: out[M, rows] = rmsnorm?(A) . W^T (+ R);  mode 1: W = [gate; up], out[M, rows/2] = silu(gate) * up;
+    mode 2: W = [q; k; v]: RoPE on q, k with `rope` [hd/2, 2]; q -> out[M, dq]; k, v -> kc / vc [M, Tmax, dkv] at row pos (+ *pos_dev)."""
+    M, K = A.shape
+    d = L.DecProjDesc()
+    d.A, d.lda, d.W, d.ldw, d.M, d.K, d.mode = L.ptr(A), _ld(A), L.ptr(W), _ld(W), M, K, mode
+    if norm_w is not None:
+        d.norm_w, d.eps = L.ptr(norm_w), eps
+    N = W.shape[0] // 2 if mode == 1 else W.shape[0]
+    d.N = N
+    if out is None:
+        out = torch.empty(M, dq if mode == 2 else N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    d.C, d.ldc, d.out_f32 = L.ptr(out), _ld(out), int(out.dtype == torch.float32)
+    if R is not None:
+        d.R, d.ldr = L.ptr(R), _ld(R)
+    if mode == 2:
+        d.dq, d.dkv, d.hd, d.rope, d.kc, d.vc, d.Tmax, d.pos = dq, dkv, hd, L.ptr(rope), L.ptr(kc), L.ptr(vc), kc.shape[1], pos
+        d.pos_dev = L.ptr(pos_dev)
+    L.check(L.load().avllm_dec_proj(C.byref(d), L.stream_ptr()))
+    return out
+
+
+def attention_decode(q, kc, vc, H, Tk, tk_dev=None, scale=None):
+    """q [B, H*hd]; kc, vc [B, Tmax, Hkv*hd] -> [B, H*hd]: softmax(q.K^T * scale) V over cache rows [0, Tk (+ *tk_dev))."""
+    B, d = q.shape
+    hd = d // H
+    Hkv = kc.shape[2] // hd
+    o = torch.empty_like(q)
+    L.check(L.load().avllm_attention_decode(L.ptr(q), _ld(q), L.ptr(kc), L.ptr(vc), L.ptr(o), _ld(o), B, H, hd, Tk, L.ptr(tk_dev), kc.shape[1],
+                                            float(scale if scale is not None else hd ** -0.5), H // Hkv, L.dt_of(q), L.stream_ptr()))
+    return o
+
+
 def step_advance(state, base_lr, total_steps, warmup_steps=0, beta1=0.9, beta2=0.95, rank=0):
     """One-thread kernel: state.step += 1 and this step's lr / bias corrections / dropout seed (include/avllm.h avllm_step_state)."""
     sc = L.Schedule(base_lr, beta1, beta2, int(warmup_steps), int(total_steps), int(rank))
