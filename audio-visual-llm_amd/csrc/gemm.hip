@@ -112,7 +112,7 @@ struct GemmArgs {
     long lda, ldb, lda2, ldb2;
     int K, K2;
     int wide_epi;        // outputs/bias/residual 16-byte aligned, N % 8 == 0: LDS-staged epilogue with 16-byte row-coalesced stores
-    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bit 1 = strict first-K-step wait, bits 4.. = start-stagger phases (1 = off)
+    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bit 1 = strict first-K-step wait, bit 2 = row-major tile order instead of 8 x 4 blocks, bits 4.. = start-stagger phases (1 = off)
     EpiParams e;
 };
 
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     int lvid = blockIdx.x, lt = 0, lm0 = 0, ln0 = 0;
     auto set_ctx = [&](int vid) __attribute__((always_inline)) {
         int tm, tn;
-        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
+        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
         lm0 = tm * HBM_; ln0 = tn * HBN_;
         const unsigned la2 = (unsigned)g.lda * 2, lb2 = (unsigned)g.ldb * 2, ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
 #pragma unroll
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         // 32p + 8fq .. +7 of row 16i + fr (acc[i][2p] = the first four, acc[i][2p+1] = the last four): bias / activation / residual on the
         // fp32 values, one rounding, one 16-byte store per pair; a store instruction covers 16 rows x 64 contiguous bytes.
         int tm, tn;
-        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn);
+        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
         const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
         stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 3);      // dbg bit 1: experiment, strict wait      // wave-uniform: every lane stores all 32 chunks
         float b[4][8];
