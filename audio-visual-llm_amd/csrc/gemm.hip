@@ -112,7 +112,7 @@ struct GemmArgs {
     long lda, ldb, lda2, ldb2;
     int K, K2;
     int wide_epi;        // outputs/bias/residual 16-byte aligned, N % 8 == 0: LDS-staged epilogue with 16-byte row-coalesced stores
-    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bit 1 = strict first-K-step wait, bit 2 = row-major tile order instead of 8 x 4 blocks, bits 4.. = start-stagger phases (1 = off)
+    int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bit 1 = strict first-K-step wait, bit 2 = row-major tile order instead of 8 x 4 blocks, bit 3 = per-XCD contiguous id ranges instead of one block per XCD and round, bits 4.. = start-stagger phases (1 = off)
     EpiParams e;
 };
 
@@ -752,9 +752,21 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     unsigned vA1[8], vB1[8];
     const bf16 *tA1, *tB1;
     int lvid = blockIdx.x, lt = 0, lm0 = 0, ln0 = 0;
+    // virtual id (blockIdx.x + k * G) -> tile id.  With a 256-workgroup grid every FULL round hands XCD x (= vid % 8: round-robin dispatch) the 32
+    // consecutive ids [256 r + 32 x, +32) = exactly one 8 x 4 tile block (tile_coords); contiguous per-XCD ranges over the whole launch
+    // (xcd_remap) start mid-block whenever ntiles / 8 is not a multiple of 32 (gate|up: 172).  The ragged last round keeps xcd_remap.
+    // Measured: gate|up 581 -> 575 us, d(down) 272.7 -> 269, lm_head 785 -> 774.
+    auto tile_id = [&](int vid) __attribute__((always_inline)) {
+        if (G == 256 && tiles_m <= 32 && tiles_m % 8 == 0 && !(g.dbg & 12)) {      // only where tile_coords walks blocks; tall shapes (M = 394000) measured 2 % slower this way
+            const int full = (ntiles >> 8) << 8;
+            if (vid < full) return (vid & ~255) + ((vid & 7) << 5) + ((vid & 255) >> 3);
+            return full + xcd_remap(vid - full, ntiles - full);
+        }
+        return xcd_remap(vid, ntiles);
+    };
     auto set_ctx = [&](int vid) __attribute__((always_inline)) {
         int tm, tn;
-        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
+        tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
         lm0 = tm * HBM_; ln0 = tn * HBN_;
         const unsigned la2 = (unsigned)g.lda * 2, lb2 = (unsigned)g.ldb * 2, ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
 #pragma unroll
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         // 32p + 8fq .. +7 of row 16i + fr (acc[i][2p] = the first four, acc[i][2p+1] = the last four): bias / activation / residual on the
         // fp32 values, one rounding, one 16-byte store per pair; a store instruction covers 16 rows x 64 contiguous bytes.
         int tm, tn;
-        tile_coords(xcd_remap(vid, ntiles), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
+        tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
         const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
         stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 3);      // dbg bit 1: experiment, strict wait      // wave-uniform: every lane stores all 32 chunks
         float b[4][8];
