@@ -15,7 +15,7 @@ from . import avsr_oracle as O
 from . import weights as Wt
 
 
-def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 12, whisper_layers: int = 4, threads: int | None = None):
+def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 32, whisper_layers: int = 4, threads: int | None = None):
     cfg = cfg or Wt.config2()
     # a 1-GPU box's CPU share is 16 cores; more torch threads than that only adds contention
     threads = threads or min(16, os.cpu_count() or 1)
