@@ -11,8 +11,14 @@ import time
 
 import torch
 
-from . import avsr_oracle as O
-from . import weights as Wt
+if __package__ in (None, ""):                       # `python oracle/cpu_baseline.py [--full]`
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import avsr_oracle as O
+    from oracle import weights as Wt
+else:
+    from . import avsr_oracle as O
+    from . import weights as Wt
 
 
 def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 32, whisper_layers: int = 4, threads: int | None = None):
