@@ -21,7 +21,7 @@ def timed(fn, n=20):
 
 dev = "cuda"
 for name, B, T, H, hd, causal, bwd in (("llama  B16 T256 H32 hd128 causal", 16, 256, 32, 128, True, True), ("clip   2000x197 H12 hd64", 2000, 197, 12, 64, False, False),
-                                       ("whisper B16 T1500 H12 hd64", 16, 1500, 12, 64, False, False)):
+                                       ("whisper B16 T1500 H12 hd64", 16, 1500, 12, 64, False, False), ("vit-l  3000x257 H16 hd64", 3000, 257, 16, 64, False, False)):
     qkv = torch.randn(B * T, 3 * H * hd, device=dev, dtype=torch.bfloat16)
     us = timed(lambda: ops.attention_fwd(qkv, B, T, H, hd, causal))
     fl = 4.0 * B * H * T * T * hd * (0.5 if causal else 1.0)
