@@ -12,6 +12,7 @@
 // ds_read_b128 row reads and the 4-row transposed reads bank-conflict free (MI355X_MICROARCH §LDS).
 #include "common.h"
 #include "avllm_internal.h"
+#include <type_traits>
 #include <cstdlib>
 
 int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
@@ -313,17 +314,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
+    // The kernel is bound by its instruction stream (profiles/r02_decode_experiments.txt), so the per-score work is trimmed: v_max3_f32 written out
+    // (fmaxf canonicalises every operand with a v_max x, x first: three instructions per two scores instead of one), and a FULL form for
+    // sequences that use every key block (CLIP: 197 tokens = 13 blocks) without the per-block "is this block inside T" branches.
+    auto max3 = [](float a, float x, float y) __attribute__((always_inline)) {
+        float r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(x), "v"(y));
+        return r;
+    };
+    auto qblock = [&](int qi, auto fullc) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(fullc)::value;             // nkb == NKB
         const int qb = w + NW * qi;
-        if (qb >= nkb) break;                                     // wave-uniform
         const int q0 = qb * 16;
         // ---- scores: S^T block kb = keys 16kb .. +15, this lane: keys 16kb + 4fq + {0..3} of query q0 + fr
         f32x4 sc[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             sc[kb] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (kb < nkb) {
+            if (FULL || kb < nkb) {
                 const char* kr = k_lds + (kb * 16 + fr) * KS + fq * 16;
                 const bf16x8 k0 = *(const bf16x8*)kr, k1 = *(const bf16x8*)(kr + 64);
                 f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi][0], zero4, 0, 0, 0);
@@ -331,25 +339,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
             }
         }
         if (T & 15) {                                             // keys past T in the last block
-            const int kb = nkb - 1;
+            if constexpr (FULL) {
 #pragma unroll
-            for (int x = 0; x < NKB; ++x)
-                if (x == kb) {
+                for (int i = 0; i < 4; ++i) sc[NKB - 1][i] = ((NKB - 1) * 16 + 4 * fq + i < T) ? sc[NKB - 1][i] : -INFINITY;
+            } else {
+                const int kb = nkb - 1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sc[x][i] = (x * 16 + 4 * fq + i < T) ? sc[x][i] : -INFINITY;
-                }
+                for (int x = 0; x < NKB; ++x)
+                    if (x == kb) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sc[x][i] = (x * 16 + 4 * fq + i < T) ? sc[x][i] : -INFINITY;
+                    }
+            }
         }
         float m = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) m = fmaxf(m, fmaxf(fmaxf(sc[kb][0], sc[kb][1]), fmaxf(sc[kb][2], sc[kb][3])));
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+        for (int kb = 0; kb < NKB; ++kb) { m = max3(m, sc[kb][0], sc[kb][1]); m = max3(m, sc[kb][2], sc[kb][3]); }
+        m = max3(m, __shfl_xor(m, 16), m);
+        m = max3(m, __shfl_xor(m, 32), m);
         const float msc = m * scale_log2e;
         // ---- P, row sum and O^T
         f32x4 lacc = zero4, oacc[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
         for (int st = 0; st < NPV; ++st) {
-            if (2 * st < nkb) {
+            if (FULL || 2 * st < nkb) {
                 bf16x8 pb;
                 const bool second = 2 * st + 1 < NKB;            // compile-time after unrolling: the last step of an odd NKB has one block
                 const f32x4 s1 = sc[second ? 2 * st + 1 : 2 * st];
@@ -388,6 +401,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
             if (q0 + row < T) *(u32x4*)(o + ((long)b * T + q0 + row) * ldo + (long)hh * HD + hf * 32 + ch * 8) = val;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+    };
+    if (nkb == NKB) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi)
+            if (w + NW * qi < NKB) qblock(qi, std::true_type{});
+    } else {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi)
+            if (w + NW * qi < nkb) qblock(qi, std::false_type{});
     }
 }
 
