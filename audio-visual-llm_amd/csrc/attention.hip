@@ -164,10 +164,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
                 s1[i] = (two && key0 + 32 <= klim) ? s1[i] : -INFINITY;
             }
         }
+        // v_max3_f32 written out: fmaxf canonicalises each operand with a v_max x, x first (three instructions per two scores instead of one)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, fmaxf(s0[i], s1[i]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32)) * scale_log2e;
-        const float m_new = fmaxf(m_run, mloc);
+        for (int i = 0; i < 16; ++i) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(mloc), "v"(s0[i]), "v"(s1[i]));
+        {
+            const float other = __shfl_xor(mloc, 32);
+            asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(mloc), "v"(other));
+        }
+        mloc *= scale_log2e;
+        float m_new;
+        asm("v_max_f32 %0, %1, %2" : "=v"(m_new) : "v"(m_run), "v"(mloc));
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         float psum = 0.f;
