@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, g = lane >> 4;
-    // The kernel is bound by its instruction stream (profiles/r02_decode_experiments.txt), so the per-score work is trimmed: v_max3_f32 written out
+    // The kernel is bound by its instruction stream (profiles/r02_experiments.txt), so the per-score work is trimmed: v_max3_f32 written out
     // (fmaxf canonicalises every operand with a v_max x, x first: three instructions per two scores instead of one), and a FULL form for
     // sequences that use every key block (CLIP: 197 tokens = 13 blocks) without the per-block "is this block inside T" branches.
     auto max3 = [](float a, float x, float y) __attribute__((always_inline)) {
