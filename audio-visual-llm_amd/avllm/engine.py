@@ -16,7 +16,13 @@ from . import ops
 
 
 class Workspace:
-    """One growable byte buffer handed to the C ABI as scratch (the library never allocates)."""
+    """One growable byte buffer handed to the C ABI as scratch (the library never allocates).
+
+    `Workspace.generation` counts reallocations of ANY workspace: a captured hipGraph holds raw pointers into these buffers, so whoever
+    replays one compares the generation it captured under with the current one and drops its graphs when they differ
+    (ClipWhisperTrainer.train_step).  Growth is monotonic, so a mix of input signatures settles after each has been seen once."""
+
+    generation = 0
 
     def __init__(self, device):
         self.device = device
@@ -24,8 +30,11 @@ class Workspace:
 
     def get(self, nbytes: int):
         if self.buf is None or self.buf.numel() < nbytes:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("workspace would grow inside a hipGraph capture (the eager warm-up step must size it first)")
             self.buf = None
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            Workspace.generation += 1
         return self.buf
 
 

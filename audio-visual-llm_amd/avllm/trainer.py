@@ -27,6 +27,7 @@ import torch
 from . import lib as L
 from . import ops
 from .dist import LoraGradReducer, is_dist
+from .engine import Workspace
 
 
 class ClipWhisperTrainer:
@@ -122,8 +123,9 @@ class ClipWhisperTrainer:
         self.sumsq.zero_()
         ops.grad_sumsq(eng.lora_g, self.sumsq)
         # NaN/Inf guard of trainer :444-452 without a host sync: a non-finite (all-reduced) loss sum or gradient norm makes the update a
-        # no-op on every rank alike (the all-reduce spreads the NaN), leaving lora_p, m and v untouched; `skipped_steps` counts them.
-        # The LR schedule and Adam's bias-correction count still advance on a skipped step (the reference's do not).
+        # no-op on every rank alike (the all-reduce spreads the NaN), leaving lora_p, m and v untouched; `skipped_steps` counts them and
+        # the device-side step count goes back by one, so neither the LR schedule nor Adam's bias corrections advance (as in the reference,
+        # which runs neither optimizer.step() nor scheduler.step() on such a batch).
         ops.adamw_step(eng.lora_p, eng.lora_g, self.m, self.v, 0.0, 0, sumsq=self.sumsq, max_norm=self.grad_clip or 0.0, wd=self.weight_decay,
                        guard=eng.acc[0:1], skipped=self.skipped, state=self.state)
         eng.pack_lora()
@@ -133,15 +135,22 @@ class ClipWhisperTrainer:
         eng = self.model.llm_engine
         self._part_fwd(audio, video, labels, prompt)
         self.reducer.reduce_counts(eng.acc)
-        if self.reducer.enabled:      # eager: one bucket per decoder layer, launched from the C callback as that layer's kernels are enqueued
+        if self.reducer.enabled and not self.use_graph:
+            # graphs off on every rank (use_graph is configuration, identical across ranks): one bucket per decoder layer, launched from
+            # the C callback as that layer's kernels are enqueued
             saved, self.bwd_pieces = self.bwd_pieces, 1
             try:
                 self._part_bwd(0, per_layer_cb=self.reducer.layer_done)
             finally:
                 self.bwd_pieces = saved
         else:
+            # with graphs on, a rank may be in this eager step (first sight of an input signature, more signatures than graph slots, a
+            # dropped graph) while another replays: both issue the SAME collectives -- one all-reduce per backward piece, same slices,
+            # same order (_replay) -- so ranks never have to agree on eager vs replay.
             for i in range(self.bwd_pieces):
                 self._part_bwd(i)
+                hi, lo = self._piece_range(i)
+                self.reducer.layers_done(lo, hi)
         self.reducer.finish()
         self._part_opt()
 
@@ -153,6 +162,7 @@ class ClipWhisperTrainer:
         for dst, src in zip(st["inputs"], (audio, video, labels, prompt)):
             if dst is not None:
                 dst.copy_(src)
+        st["generation"] = Workspace.generation          # the graphs below hold raw pointers into the engines' workspaces as they are NOW
         pool = torch.cuda.graph_pool_handle()
         a, v, lab, pr = st["inputs"]
         torch.cuda.synchronize()
@@ -214,10 +224,17 @@ class ClipWhisperTrainer:
         if use_graph:
             key = self._signature(audio, video, labels, prompt)
             st = self._graphs.get(key)
+            if isinstance(st, dict) and st["generation"] != Workspace.generation:
+                # some workspace was reallocated since capture (a larger batch / more frames / generate() in between): every captured
+                # graph may point into freed memory.  Drop them all; each signature is re-captured at its next-but-one visit.
+                self._graphs = {k: "warm" for k in self._graphs}
+                st = "stale"                             # this call runs eager and re-sizes nothing (workspaces only grow)
             if st is None and len(self._graphs) < 4:
                 self._graphs[key] = st = "warm"          # first sight of a signature: eager (sizes every workspace); captured at the second
             elif st == "warm":
                 self._graphs[key] = st = self._capture(audio, video, labels, prompt)
+                if st["generation"] != Workspace.generation:         # cannot happen (Workspace.get refuses to grow under capture); belt and braces
+                    self._graphs[key] = st = "warm"
         if isinstance(st, dict):
             for dst, src in zip(st["inputs"], (audio, video, labels, prompt)):
                 if dst is not None and src.data_ptr() != dst.data_ptr():
@@ -230,6 +247,12 @@ class ClipWhisperTrainer:
     @property
     def skipped_steps(self):
         return int(self.skipped.item())
+
+    def _sync_step(self):
+        """global_step := the optimizer steps actually taken (device-side count: skipped steps do not advance it).  One host sync; called
+        where the host already waits for the device (log interval, checkpoint)."""
+        self.global_step = int(self.state.view(torch.int32)[0].item())
+        return self.global_step
 
     def _all_ranks_ok(self, ok):
         """Data-parallel runs: a batch is trained on only if EVERY rank could unpack its share -- a rank that skipped on its own would
@@ -244,7 +267,7 @@ class ClipWhisperTrainer:
         self.model.train()
         total, n, t0 = 0.0, 0, time.time()
         pending = []
-        failures = 0
+        failures = unstable = worst = 0
         for i, batch in enumerate(self.train_dataloader):
             # the reference logs and skips a batch on ANY exception (:492-507).  Host-side preparation (everything before the first
             # collective) is where data errors surface; under DDP the skip is agreed between ranks first.
@@ -261,7 +284,7 @@ class ClipWhisperTrainer:
                 continue
             try:
                 loss = self.train_step(*unpacked)
-            except (ValueError, AssertionError) as e:
+            except Exception as e:                               # the reference logs and skips on ANY exception (:492-507)
                 if is_dist():
                     raise                                        # mid-step: the other ranks are already inside the collectives
                 logging.error(f"Error in batch {i}: {e}")
@@ -274,8 +297,20 @@ class ClipWhisperTrainer:
             if (i + 1) % self.log_interval == 0 or i + 1 == len(self.train_dataloader):
                 vals = torch.stack(pending).float().cpu()
                 pending.clear()
-                ok = vals[torch.isfinite(vals)]
+                self._sync_step()
+                fin = torch.isfinite(vals)
+                ok = vals[fin]
                 total += float(ok.sum()); n += int(ok.numel())
+                # trainer :444-452: a NaN loss skips the batch; more than 5 unstable batches in a row stop the epoch.  The losses stay on
+                # the device between log intervals (no per-step host sync), so the streak is examined here, over the interval just read.
+                for f in fin.tolist():
+                    unstable = 0 if f else unstable + 1
+                    worst = max(worst, unstable)
+                if not bool(fin.all()):
+                    logging.warning(f"NaN loss detected in {int((~fin).sum())} batch(es) up to batch {i}; {self.skipped_steps} optimizer step(s) skipped so far")
+                if worst > 5:
+                    logging.error("Too many unstable batches. Stopping epoch.")
+                    break
                 logging.info(f"epoch {epoch} batch {i + 1}/{len(self.train_dataloader)} loss {float(vals[-1]):.4f} "
                              f"avg {total / max(1, n):.4f} lr {self.lr_at(self.global_step):.3e} {(time.time() - t0) / (i + 1):.3f}s/it")
         return total / max(1, n)
@@ -312,6 +347,7 @@ class ClipWhisperTrainer:
         if is_dist() and torch.distributed.get_rank() != 0:
             return
         os.makedirs(self.output_dir, exist_ok=True)
+        self._sync_step()
         path = os.path.join(self.output_dir, name)
         eng = self.model.llm_engine
         state, n = {}, 0

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the AV->LLM hot path.
 // Wavefront = 64 lanes everywhere; no other architecture is supported.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -17,6 +18,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define AV_WAVE 64
+
+// A/B switches for tools/*_bench.py: read ONCE per process, at first use (never per layer or per launch).  Knobs that change what a
+// production kernel computes or stores (AVLLM_GEMM_DBG) exist only in builds made with -DAVLLM_EXPERIMENT_KNOBS.
+#define AV_ENV_INT(name, dflt) ([] { static const int v_ = getenv(name) ? atoi(getenv(name)) : (dflt); return v_; }())
+#define AV_ENV_SET(name) ([] { static const bool v_ = getenv(name) != nullptr; return v_; }())
 
 // ---- status / error string (thread local), SURVEY.md §8b "Errors" row
 #define AV_OK 0

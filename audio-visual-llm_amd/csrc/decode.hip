@@ -215,7 +215,11 @@ __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
         const float c = a.rope[2 * i], sn = a.rope[2 * i + 1];
         o = nn < 8 ? s * c - other * sn : s * c + other * sn;
     }
+    // position from device memory: the host could not check it.  A step replayed past the end of the cache writes nothing (the cache
+    // rows of the last valid position stay as they are) instead of running over [B, Tmax, dkv]; attn_decode1_kernel clamps its length alike.
+    const bool in_cache = pos >= 0 && pos < a.Tmax;
     if (ocol < a.dq) ((bf16*)a.C)[(long)m * a.ldc + ocol] = (bf16)o;
+    else if (!in_cache) return;
     else if (ocol < a.dq + a.dkv) a.kc[((long)m * a.Tmax + pos) * a.dkv + ocol - a.dq] = (bf16)o;
     else a.vc[((long)m * a.Tmax + pos) * a.dkv + ocol - a.dq - a.dkv] = (bf16)o;
 }
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode1_kernel(const T* __restri
     __shared__ float pm[NW], pl[NW];
     const int h = blockIdx.x, b = blockIdx.y, d = (H / GQ) * hd;
     if (tk_dev) Tk += *tk_dev;
+    Tk = Tk > Tmax ? Tmax : Tk;                      // a device-side length the host could not check never reads past the cache
     const int G = hd >> 3, R = NW * 64 / G;
     const int tid = threadIdx.x, dc = tid % G, rsub = tid / G;
     float qv[8];
@@ -321,8 +326,8 @@ bool av_dec_proj_supported(int dtype, int M, int K, int N, int mode, int hd) {
 static int dec_launch(DecArgs& a, hipStream_t st) {
     const int grid = a.mode == DEC_SWIGLU ? a.N / 8 : a.N / 16;
 #define DEC_LAUNCH(NORMV, ALV) hipLaunchKernelGGL((dec_proj_kernel<NORMV, ALV>), dim3(grid), dim3(DW * 64), 0, st, a)
-    const char* ev = getenv("AVLLM_DEC_AL");       // experiment knob: force the activation-load form (4 = one load per step)
-    const int al = ev ? atoi(ev) : (a.M <= 4 ? 1 : a.M <= 8 ? 2 : 4);
+    const int ev = AV_ENV_INT("AVLLM_DEC_AL", 0);       // experiment knob: force the activation-load form (4 = one load per step)
+    const int al = ev ? ev : (a.M <= 4 ? 1 : a.M <= 8 ? 2 : 4);
     if (a.norm_w) { if (al == 1 && a.M <= 4) DEC_LAUNCH(true, 1); else if (al <= 2 && a.M <= 8) DEC_LAUNCH(true, 2); else DEC_LAUNCH(true, 4); }
     else { if (al == 1 && a.M <= 4) DEC_LAUNCH(false, 1); else if (al <= 2 && a.M <= 8) DEC_LAUNCH(false, 2); else DEC_LAUNCH(false, 4); }
 #undef DEC_LAUNCH

@@ -62,7 +62,7 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
     for (int l = 0; l < layers; ++l) {
         const avllm_enc_layer& P = L[l];
         AV_CHECK_ARG(!fp8 || (P.wqkv8 && P.sqkv8 && P.wo8 && P.so8 && P.w18 && P.s18 && P.w28 && P.s28), "encoder layer %d: fp8 mode without fp8 weight images", l);
-        const bool nq = fp8 && d % 128 == 0 && d <= 8192 && !getenv("AVLLM_F8_UNFUSED_QUANT");      // LayerNorm straight to e4m3 + scales (fp8.hip norm_mxq_kernel)
+        const bool nq = fp8 && d % 128 == 0 && d <= 8192 && !AV_ENV_SET("AVLLM_F8_UNFUSED_QUANT");      // LayerNorm straight to e4m3 + scales (fp8.hip norm_mxq_kernel)
         if (nq) AV_TRY(av_norm_mxq(b.x, P.ln1_w, P.ln1_b, nullptr, nullptr, b.f8.q, d, b.f8.s, M, d, eps, st));
         else AV_TRY(av_layernorm(b.x, P.ln1_w, P.ln1_b, b.xn, M, d, eps, dtype, st));
         avllm_gemm_desc g;
@@ -106,7 +106,7 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
                 F8Buf ffq;
                 ffq.q = b.ff; ffq.s = (char*)b.ff + (((size_t)M * ffn + 255) & ~(size_t)255);
                 q1.Cq = ffq.q; q1.SCq = ffq.s; q1.ldcq = ffn;
-                if (!getenv("AVLLM_F8_UNFUSED_QUANT") && avllm_gemm_f8_takes_quantised_output(&q1) && (size_t)M * ffn + 256 + avllm_mx_scale_bytes((int)M, ffn) <= (size_t)M * ffn * es) {
+                if (!AV_ENV_SET("AVLLM_F8_UNFUSED_QUANT") && avllm_gemm_f8_takes_quantised_output(&q1) && (size_t)M * ffn + 256 + avllm_mx_scale_bytes((int)M, ffn) <= (size_t)M * ffn * es) {
                     AV_TRY(av_gemm_f8(&q1, st));
                     AV_TRY(f8_proj(ffq, (int)M, ffn, P.w28, P.s28, d, b.x, d, P.b2, AV_ACT_NONE, b.x, d, st));
                     continue;
@@ -383,7 +383,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
         }
         // all three rank-side products t_j = s * dropout_j(xn1) A_j^T in one launch (xn1 read once): csrc/lora_batch.hip
         const bool batch_qkv = !fp8 && dt == AV_BF16 && P.lora[0].A_pad && P.lora[1].A_pad && P.lora[2].A_pad && (!drop || fuse_drop) &&
-                               d % 256 == 0 && av_lora_batch_supported(dt, m->lora_r, 3) && !getenv("AVLLM_LORA_UNBATCHED");
+                               d % 256 == 0 && av_lora_batch_supported(dt, m->lora_r, 3) && !AV_ENV_SET("AVLLM_LORA_UNBATCHED");
         if (batch_qkv) {
             const void* Ap[3] = {a.xn1, a.xn1, a.xn1}; const long la[3] = {d, d, d}; const int Kk[3] = {d, d, d};
             const void* Bp[3] = {P.lora[0].A_pad, P.lora[1].A_pad, P.lora[2].A_pad}; const long lb[3] = {d, d, d};
@@ -539,7 +539,7 @@ extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* 
         // ---- q,k,v projections (+LoRA)
         bool any = false, contiguous = true;
         const bool batch_bwd = dt == AV_BF16 && P.lora[0].A_pad && P.lora[1].A_pad && P.lora[2].A_pad && (!drop || fuse_drop) && d % 256 == 0 &&
-                               dkv % 256 == 0 && av_lora_batch_supported(dt, R, 3) && !getenv("AVLLM_LORA_UNBATCHED");
+                               dkv % 256 == 0 && av_lora_batch_supported(dt, R, 3) && !AV_ENV_SET("AVLLM_LORA_UNBATCHED");
         if (batch_bwd) {      // three launches for the three adapters' dB, dt and dA (csrc/lora_batch.hip) instead of nine
             any = true;
             const void* Tq[3]; long ltq[3]; float* gBp[3]; long lgb[3]; int c0[3], nc[3];
@@ -701,7 +701,7 @@ extern "C" int avllm_llama_prefill(const avllm_llama* m, const void* x, int32_t 
 
 // One decoder block of a token step in 5 launches (decode.hip): bf16, B <= 16 sequences, no adapters on this layer.
 static bool llama_decode_fused_ok(const avllm_llama* m, int B) {
-    const bool off = getenv("AVLLM_DECODE_FUSED") && atoi(getenv("AVLLM_DECODE_FUSED")) == 0;
+    const bool off = AV_ENV_INT("AVLLM_DECODE_FUSED", 1) == 0;
     if (off || m->dtype != AV_BF16 || B > 16) return false;
     const int hd = m->d / m->heads;
     if (!(hd == 64 || hd == 128)) return false;

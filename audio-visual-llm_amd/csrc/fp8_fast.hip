@@ -374,8 +374,11 @@ int av_gemm_f8_fast(const avllm_gemm_f8_desc* d, hipStream_t st, bool* taken) {
     F8Args g;
     g.A = (const uint8_t*)d->A; g.B = (const uint8_t*)d->B; g.SA = (const uint32_t*)d->SA; g.SB = (const uint32_t*)d->SB;
     g.lda = d->lda; g.ldb = d->ldb; g.K = d->K; g.RBA = f8_groups(d->M); g.RBB = f8_groups(d->N);
-    static const int dbg_env = getenv("AVLLM_GEMM_DBG") ? atoi(getenv("AVLLM_GEMM_DBG")) : 0;
-    g.dbg = dbg_env;
+#ifdef AVLLM_EXPERIMENT_KNOBS
+    g.dbg = AV_ENV_INT("AVLLM_GEMM_DBG", 0);
+#else
+    g.dbg = 0;
+#endif
     g.C = d->C; g.ldc = d->ldc; g.bias = d->bias; g.R = d->R; g.ldr = d->ldr; g.act = d->act; g.M = d->M; g.N = d->N;
     g.Cq = (uint8_t*)d->Cq; g.SCq = (uint32_t*)d->SCq; g.ldcq = d->ldcq;
     hipLaunchKernelGGL(gemm_f8_wp_kernel, dim3(xtiles < ncu[dev] ? xtiles : ncu[dev]), dim3(256), F8_LDS, st, g);

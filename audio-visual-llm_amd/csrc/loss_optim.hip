@@ -127,7 +127,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     if (bad) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (skipped) atomicAdd(skipped, 1.0f);
-            if (state) atomicAdd(&state->skipped, 1.0f);
+            // a skipped step is not an optimizer step: the reference runs neither optimizer.step() nor scheduler.step() on it
+            // (trainer/clip_whisper_trainer.py:444-452), so the step count that drives lr and the bias corrections goes back by one.
+            // Nobody else reads state->step in this launch (lr / bc1 / bc2_sqrt were copied above; every other thread returns).
+            if (state) { atomicAdd(&state->skipped, 1.0f); if (state->step > 0) state->step -= 1; }
         }
         return;
     }
@@ -257,7 +260,8 @@ __global__ void step_advance_kernel(avllm_step_state* s, avllm_schedule c) {
     s->lr = lr;
     s->bc1 = 1.0f - powf(c.beta1, (float)step);
     s->bc2_sqrt = sqrtf(1.0f - powf(c.beta2, (float)step));
-    s->dropout_seed = step * 0x9E3779B1u + c.rank * 0x85EBCA6Bu + 12345u;
+    // + the skipped count: a step that is retried after a skipped one (same step number) draws fresh masks
+    s->dropout_seed = (step + (uint32_t)s->skipped) * 0x9E3779B1u + c.rank * 0x85EBCA6Bu + 12345u;
 }
 
 int av_step_advance(avllm_step_state* state, const avllm_schedule* sched, hipStream_t st) {

@@ -8,6 +8,7 @@ CSRC = os.path.join(ROOT, "audio-visual-llm_amd", "csrc")
 OUT = os.path.join(ROOT, "audio-visual-llm_amd", "avllm", "libavllm.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+FLAGS += os.environ.get("AVLLM_EXTRA_FLAGS", "").split()        # e.g. -DAVLLM_EXPERIMENT_KNOBS for tools/gemm_epi_experiment.sh (use --force)
 
 
 def stale(target, deps):

@@ -130,7 +130,7 @@ int avllm_norm_mxq(const void* x, const void* w, const void* b, void* y, float* 
  *   lr           = cosine schedule of _setup_optimizer :210-230 at (step-1): base_lr*(1+cos(pi*s/total))/2, or linear warm-up over
  *                  warmup_steps followed by the cosine over the remaining steps (transformers get_cosine_schedule_with_warmup)
  *   bc1, bc2_sqrt = 1-beta1^step, sqrt(1-beta2^step)                           (torch.optim.AdamW bias corrections)
- *   dropout_seed = step*0x9E3779B1 + rank*0x85EBCA6B + 12345                   (this step's LoRA dropout mask seed)
+ *   dropout_seed = (step+skipped)*0x9E3779B1 + rank*0x85EBCA6B + 12345         (this step's LoRA dropout mask seed)
  * Consumers: avllm_llama.dropout_seed_dev (-> &state->dropout_seed), avllm_adamw_step(state). */
 typedef struct avllm_step_state {
     uint32_t step;                      /* optimizer steps started (1-based after the first advance) */
@@ -219,8 +219,9 @@ int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
 int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t step, const float* sumsq, float max_norm,
                      float grad_prescale, const float* guard, float* skipped, const avllm_step_state* state_dev, void* stream);
-/* state_dev != NULL: lr and the bias corrections come from *state_dev (the `lr` and `step` arguments are ignored) and skipped steps
- * are also counted in state_dev->skipped. */
+/* state_dev != NULL: lr and the bias corrections come from *state_dev (the `lr` and `step` arguments are ignored); a skipped step is
+ * also counted in state_dev->skipped and takes state_dev->step back by one, so that neither the schedule nor Adam's bias corrections
+ * advance on it (the reference skips optimizer.step() AND scheduler.step(), trainer/clip_whisper_trainer.py:444-452). */
 /* build the four padded operand images of one LoRA pair from the fp32 masters A [r,din], B [dout,r]:
  * A_pad [64,din], AT_pad [din,64] (row stride ld_at), B_pad [dout,64], BT_pad [64,dout] in `dtype` */
 int avllm_lora_pack(const float* A, const float* Bm, int32_t r, int32_t din, int32_t dout, void* A_pad, void* AT_pad,
