@@ -11,7 +11,7 @@ random tensors of the true shapes (no checkpoints offline).  All arithmetic runs
 
 Rank 0 prints ONE JSON line (contract in the task statement): whole-job samples/s, plus
   roofline     -- the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / summed HIP-event time, live, vs 2.5 PF/s
-  cpu_baseline -- the CPU oracle timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+  cpu_baseline -- the CPU oracle timed on this box's host cores: ONE complete B=1 train step at full depth (rank 0, N=1 only).
 """
 import argparse
 import ctypes
@@ -189,8 +189,9 @@ def main():
                     "projections of the forward pass; use with --whisper openai/whisper-large-v3 --clip openai/clip-vit-large-patch14 "
                     "--llm mistralai/Mistral-7B-v0.1 --frames 750)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"], help="sample: bounded slice of one B=1 step scaled up (default, ~20 s); "
-                    "full: one complete B=1 train step of the oracle at full depth (~1-2 min of host time)")
+    ap.add_argument("--cpu-baseline", default="full", choices=["sample", "full"], help="full (default, BASELINE.md §2): one complete B=1 train step of the oracle "
+                    "at full depth, every frame, forward + backward (~20-35 s of host time); sample: a bounded slice of one B=1 step extrapolated by layer / "
+                    "frame counts (~6 s; reads ~1.3x faster than the full step)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the second leg (batches arriving in pinned host memory as raw uint8 frames + samples)")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg")
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -21,6 +21,18 @@ else:
     from . import weights as Wt
 
 
+def cpu_model():
+    """The host CPU's model string ("core count and CPU model printed in the report")."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 32, whisper_layers: int = 4, threads: int | None = None):
     cfg = cfg or Wt.config2()
     # a 1-GPU box's CPU share is 16 cores; more torch threads than that only adds contention
@@ -63,7 +75,7 @@ def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 
     llama_s = (layer_f + layer_b) * cfg.llama.layers + 3 * t_head
     total = whisper_s + clip_s + llama_s
     return {
-        "value": 1.0 / total, "unit": "samples/s", "cores": threads, "kind": "port",
+        "value": 1.0 / total, "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
         "sample": (f"B=1: Whisper stem+{whisper_layers}/{cfg.whisper.layers} layers, CLIP {sample_frames}/{frames} frames, "
                    f"1/{cfg.llama.layers} Llama layer fwd+bwd + lm_head/CE at S=256, fp32 torch CPU oracle; extrapolated by "
                    f"layer/frame counts"),
@@ -104,7 +116,7 @@ def run_full(cfg: Wt.ModelCfg | None = None, frames: int = 125, threads: int | N
     O.train_step_grads(W, cfg, audio, video, prompt, labels)
     step_s = time.time() - t0
     split["llama_fwd_bwd"] = round(step_s - split["whisper"] - split["clip"], 3)
-    return {"value": 1.0 / step_s, "unit": "samples/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / step_s, "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"one full B=1 train step ({frames} frames, all {cfg.whisper.layers}+{cfg.clip.layers}+{cfg.llama.layers} layers, forward + backward), fp32 torch CPU "
                       "oracle; the decoder layers share one set of random tensors", "split_s": split, "measured_s": round(time.time() - t_all, 2),
             "setup_s": round(t_setup, 2)}

@@ -25,6 +25,8 @@ def parse_args():
     p.add_argument("--no_lora", action="store_true"); p.add_argument("--lora_r", type=int); p.add_argument("--lora_alpha", type=int)
     p.add_argument("--connector_type", default=None); p.add_argument("--max_grad_norm", type=float)
     p.add_argument("--log_interval", type=int); p.add_argument("--save_every", type=int); p.add_argument("--resume_from")
+    p.add_argument("--save_steps", type=int, default=None, help="stored by the trainer and never acted on, as in the reference (clip_whisper_trainer.py:94-102)")
+    p.add_argument("--log_param_updates", action="store_true", help="accepted for command-line compatibility; the reference stores it and never reads it (:118)")
     p.add_argument("--seed", type=int); p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic clips")
     p.add_argument("--frames", type=int, default=125); p.add_argument("--tiny", action="store_true")
     p.add_argument("--synthetic-weights", action="store_true",
@@ -58,7 +60,8 @@ def main():
                             "clip_model": a.clip_model, "modality": a.modality, "batch_size": a.batch_size, "num_epochs": a.max_epochs,
                             "learning_rate": a.learning_rate, "max_seq_len": a.max_seq_len, "use_fp16": a.fp16, "use_4bit": a.use_4bit,
                             "lora_r": a.lora_r, "lora_alpha": a.lora_alpha, "connector_type": a.connector_type,
-                            "max_grad_norm": a.max_grad_norm, "log_interval": a.log_interval, "save_every": a.save_every, "seed": a.seed})
+                            "max_grad_norm": a.max_grad_norm, "log_interval": a.log_interval, "save_every": a.save_every, "seed": a.seed,
+                            "save_steps": a.save_steps, "log_param_updates": a.log_param_updates or None})
     os.makedirs(cfg["output_dir"], exist_ok=True)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s",
                         handlers=[logging.StreamHandler(), logging.FileHandler(os.path.join(cfg["output_dir"], "training.log"))])
@@ -98,7 +101,8 @@ def main():
     tr = ClipWhisperTrainer(model, dl, vdl, learning_rate=float(cfg.get("learning_rate", 5e-5)), weight_decay=float(cfg.get("weight_decay", 0.01)),
                             max_epochs=cfg.get("num_epochs", 10), output_dir=cfg["output_dir"], device=f"cuda:{local}", fp16=bool(cfg.get("use_fp16")),
                             grad_accum_steps=cfg.get("grad_accum_steps", 1), log_interval=cfg.get("log_interval", 10), save_every=cfg.get("save_every", 1),
-                            grad_clip=float(cfg.get("max_grad_norm", 0.5)), warmup_steps=cfg.get("warmup_steps", 0))
+                            grad_clip=float(cfg.get("max_grad_norm", 0.5)), warmup_steps=cfg.get("warmup_steps", 0),
+                            save_steps=cfg.get("save_steps", None), log_param_updates=bool(cfg.get("log_param_updates", False)))
     if a.resume_from:
         tr.load_checkpoint(a.resume_from)
     print(tr.train())

@@ -54,14 +54,23 @@ def test_cli_train_then_decode_from_manifests(dev, tmp_path):
     out, dec = tmp_path / "out", tmp_path / "dec"
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, os.path.join(root, "scripts/clip_whisper/train.py"), "--tiny", "--data_path", str(data), "--batch_size", "2",
-                        "--max_epochs", "1", "--output_dir", str(out)], capture_output=True, text=True, env=env, timeout=300)
+                        "--max_epochs", "1", "--output_dir", str(out), "--save_steps", "100", "--log_param_updates"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     ck = torch.load(out / "model_final.pt", map_location="cpu", weights_only=True)
     keys = ck["model_state_dict"].keys()
     assert "audio_connector.linear.weight" in keys and any(k.endswith("self_attn.q_proj.lora_A.default.weight") for k in keys)
     assert os.path.exists(out / "training.log")
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts/clip_whisper/decode.py"), "--tiny", "--data_path", str(data), "--batch_size", "2",
-                        "--max_new_tokens", "4", "--model_path", str(out / "model_final.pt"), "--output_dir", str(dec)],
+    # the reference's own command line (decode.py:42-66), flag for flag; --tiny / --data_path are this build's additions (no checkpoints
+    # offline; the toy media sit next to the manifest rather than one directory above it)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts/clip_whisper/decode.py"), "--model_path", str(out / "model_final.pt"),
+                        "--test_data", str(data / "test.tsv"), "--test_wrd", str(data / "test.wrd"), "--output_dir", str(dec), "--modality", "both",
+                        "--batch_size", "2", "--max_new_tokens", "4", "--temperature", "1.0", "--device", "cuda", "--seed", "42", "--verbose",
+                        "--whisper_model", "openai/whisper-small", "--clip_model", "openai/clip-vit-base-patch16", "--llm_model", "meta-llama/Llama-2-7b-hf",
+                        "--output_file", "decode_results.json", "--tiny", "--data_path", str(data)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "corpus WER" in r.stdout and glob.glob(str(dec / "results_*.txt")) and glob.glob(str(dec / "wer_*.txt"))
+    assert "Overall WER:" in r.stdout and "UTT: id0" in r.stdout and "REF: hello world 0" in r.stdout
+    res = open(glob.glob(str(dec / "results_*.txt"))[0]).read()
+    assert res.startswith("Modality: both\nOverall WER: ") and "Utterance ID" in res and "hello world 3" in res
+    assert open(glob.glob(str(dec / "wer_*.txt"))[0]).read().split("\n")[1] == "Total samples: 4"
+    assert glob.glob(str(dec / "decode_*.log")) and os.path.exists(dec / "decode_results.json")

@@ -30,6 +30,15 @@ def _model(precision="fp32", dropout=0.0):
     return oc, m
 
 
+def _long(batch, oc):
+    """Long transcripts: a NaN enters through the audio frames, i.e. behind the pooled prompt rows; with causal attention only label
+    positions past them can see it (a short transcript scores none of them and trains normally -- as the reference would)."""
+    audio, video, labels, prompt = batch
+    labels = labels.clone()
+    labels[:, 1:200] = torch.randint(3, oc.llama.vocab, (labels.shape[0], 199), generator=torch.Generator().manual_seed(5))
+    return audio, video, labels, prompt
+
+
 def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
@@ -68,7 +77,7 @@ def test_replay_after_a_larger_signature_regrew_the_workspaces(dev):
 def test_nonfinite_batch_skips_update_and_does_not_advance_schedule(dev):
     from avllm.trainer import ClipWhisperTrainer
     oc = Wt.tiny()
-    good = [Wt.synthetic_batch(oc, 2, 3, seed=s) for s in (1, 2, 3, 4)]
+    good = [_long(Wt.synthetic_batch(oc, 2, 3, seed=s), oc) for s in (1, 2, 3, 4)]
     bad = [t.clone() if t is not None else None for t in good[1]]
     bad[0][0, 0, 0] = float("nan")                               # one NaN in the mel of clip 0
     for graph in (False, True):
@@ -93,7 +102,7 @@ def test_nonfinite_batch_skips_update_and_does_not_advance_schedule(dev):
 def test_train_epoch_stops_after_more_than_five_unstable_batches(dev, caplog):
     from avllm.trainer import ClipWhisperTrainer
     oc = Wt.tiny()
-    good = Wt.synthetic_batch(oc, 2, 3, seed=1)
+    good = _long(Wt.synthetic_batch(oc, 2, 3, seed=1), oc)
     bad = [t.clone() for t in good]
     bad[0][:] = float("nan")
     mk = lambda b: {"audio": b[0].to(dev), "video": b[1].to(dev), "labels": b[2].to(dev), "prompt": b[3].to(dev)}
