@@ -384,6 +384,10 @@ class LlamaEngine:
         per_layer = (d + 2 * self.dkv) * d + d * d + 2 * f * d + d * f
         return (self.cfg.layers * per_layer + self.cfg.vocab * d) * (4 if self.dtype == torch.float32 else 2)
 
+    def decode_is_fused(self, B):
+        """True when a token step of B sequences takes the fused bf16 path (tests and benchmarks assert which path they measured)."""
+        return bool(L.load().avllm_llama_decode_is_fused(C.byref(self.desc), B))
+
     def alloc_cache(self, B, Tmax):
         shape = (self.cfg.layers, B, Tmax, self.dkv)
         return torch.empty(shape, dtype=self.dtype, device=self.device), torch.empty(shape, dtype=self.dtype, device=self.device)

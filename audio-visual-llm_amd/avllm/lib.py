@@ -71,7 +71,8 @@ class DecProjDesc(C.Structure):
     """avllm_dec_proj_desc (include/avllm.h): one projection of a decode token step."""
     _fields_ = [("A", vp), ("lda", i64), ("W", vp), ("ldw", i64), ("norm_w", vp), ("eps", f32), ("M", i32), ("K", i32), ("N", i32), ("mode", i32),
                 ("C", vp), ("ldc", i64), ("out_f32", i32), ("R", vp), ("ldr", i64), ("dq", i32), ("dkv", i32), ("hd", i32), ("rope", vp),
-                ("kc", vp), ("vc", vp), ("Tmax", i32), ("pos", i32), ("pos_dev", vp)]
+                ("kc", vp), ("vc", vp), ("Tmax", i32), ("pos", i32), ("pos_dev", vp),
+                ("lora_t", vp), ("ld_lora_t", i64), ("lora_b", vp * 3), ("lora_r", i32), ("lora_scale", f32)]
 
 
 class StepState(C.Structure):
@@ -90,6 +91,7 @@ _SIGS = {
     "avllm_version": ([], i32),
     "avllm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "avllm_set_gemm_variant": ([i32], i32),
+    "avllm_set_knob": ([C.c_char_p, i32], i32),
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),
     "avllm_gemm_tn_drop": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, C.c_uint32, f32, i32, vp], i32),
     "avllm_logmel_table_bytes": ([], C.c_size_t),
@@ -145,6 +147,7 @@ _SIGS = {
     "avllm_llama_prefill": ([C.POINTER(Llama), vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp], i32),
     "avllm_llama_decode_step": ([C.POINTER(Llama), vp, i32, i32, vp, vp, i32, vp, vp, sz, vp], i32),
     "avllm_llama_decode_step_at": ([C.POINTER(Llama), vp, i32, i32, vp, vp, vp, i32, vp, vp, sz, vp], i32),
+    "avllm_llama_decode_is_fused": ([C.POINTER(Llama), i32], i32),
     "avllm_pos_advance": ([vp, i32, vp], i32),
     "avllm_dec_proj": ([C.POINTER(DecProjDesc), vp], i32),
     "avllm_gemm_f8_takes_quantised_output": ([C.POINTER(GemmF8Desc)], i32),
@@ -180,6 +183,24 @@ def load():
 
 class AvllmError(RuntimeError):
     pass
+
+
+class knob:
+    """with knob("DECODE_FUSED", 0): ...   -- one of the library's A/B switches for the duration of the block (include/avllm.h
+    avllm_set_knob; the table is otherwise filled once per process from AVLLM_<NAME>)."""
+    _defaults = {"DECODE_FUSED": 1, "DEC_AL": 0, "LORA_UNBATCHED": 0, "F8_UNFUSED_QUANT": 0, "F8_FAST": 1, "ATTN_SHORT": 1,
+                 "NARROW_EPILOGUE": 0, "TN_CHUNK": 0, "GEMM_DBG": 0}
+
+    def __init__(self, name, value):
+        self.name, self.value = name, int(value)
+
+    def __enter__(self):
+        check(load().avllm_set_knob(self.name.encode(), self.value))
+        return self
+
+    def __exit__(self, *a):
+        env = os.environ.get("AVLLM_" + self.name)
+        check(load().avllm_set_knob(self.name.encode(), int(env) if env is not None else self._defaults[self.name]))
 
 
 def check(rc: int):

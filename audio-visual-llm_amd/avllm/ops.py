@@ -294,7 +294,8 @@ def norm_mxq(x, w, b=None, eps=1e-5, want_y=False, want_rstd=False):
     return q, sc, y, rstd
 
 
-def dec_proj(A, W, mode=0, norm_w=None, eps=1e-5, R=None, out=None, out_f32=False, rope=None, kc=None, vc=None, pos=0, pos_dev=None, dq=0, dkv=0, hd=0):
+def dec_proj(A, W, mode=0, norm_w=None, eps=1e-5, R=None, out=None, out_f32=False, rope=None, kc=None, vc=None, pos=0, pos_dev=None, dq=0, dkv=0, hd=0,
+             lora_t=None, lora_b=None, lora_r=0, lora_scale=0.0):
     """One projection of a decode token step (avllm_dec_proj): A [M<=16, K] bf16, W [rows, K] bf16.
     mode 0: out[M, rows] = rmsnorm?(A) . W^T (+ R);  mode 1: W = [gate; up], out[M, rows/2] = silu(gate) * up;
     mode 2: W = [q; k; v]: RoPE on q, k with `rope` [hd/2, 2]; q -> out[M, dq]; k, v -> kc / vc [M, Tmax, dkv] at row pos (+ *pos_dev)."""
@@ -313,6 +314,10 @@ def dec_proj(A, W, mode=0, norm_w=None, eps=1e-5, R=None, out=None, out_f32=Fals
     if mode == 2:
         d.dq, d.dkv, d.hd, d.rope, d.kc, d.vc, d.Tmax, d.pos = dq, dkv, hd, L.ptr(rope), L.ptr(kc), L.ptr(vc), kc.shape[1], pos
         d.pos_dev = L.ptr(pos_dev)
+    if lora_t is not None:          # adapters: lora_t [M, >= 64 per module] f32 rank-side products, lora_b = padded B images [rows, 64] (one, or q / k / v)
+        d.lora_t, d.ld_lora_t, d.lora_r, d.lora_scale = L.ptr(lora_t), _ld(lora_t), lora_r, lora_scale
+        for j, b in enumerate(lora_b):
+            d.lora_b[j] = L.ptr(b)
     L.check(L.load().avllm_dec_proj(C.byref(d), L.stream_ptr()))
     return out
 

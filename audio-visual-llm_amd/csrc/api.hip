@@ -14,8 +14,36 @@ int av_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- experiment knobs (common.h AvKnob)
+#include <mutex>
+#include <string.h>
+static const struct { const char* name; int dflt; } g_knob_def[AV_KNOB_COUNT] = {
+    {"DECODE_FUSED", 1}, {"DEC_AL", 0}, {"LORA_UNBATCHED", 0}, {"F8_UNFUSED_QUANT", 0}, {"F8_FAST", 1}, {"ATTN_SHORT", 1},
+    {"NARROW_EPILOGUE", 0}, {"TN_CHUNK", 0}, {"GEMM_DBG", 0}};
+static int g_knob[AV_KNOB_COUNT];
+static std::once_flag g_knob_once;
+static void knob_init() {
+    for (int i = 0; i < AV_KNOB_COUNT; ++i) {
+        char env[64];
+        snprintf(env, sizeof(env), "AVLLM_%s", g_knob_def[i].name);
+        const char* e = getenv(env);
+        g_knob[i] = e ? atoi(e) : g_knob_def[i].dflt;
+    }
+}
+int av_knob(int id) {
+    std::call_once(g_knob_once, knob_init);
+    return g_knob[id];
+}
+
 #define ST ((hipStream_t)stream)
 extern "C" {
+int avllm_set_knob(const char* name, int32_t value) {
+    AV_CHECK_ARG(name, "set_knob: null name");
+    std::call_once(g_knob_once, knob_init);
+    for (int i = 0; i < AV_KNOB_COUNT; ++i)
+        if (!strcmp(name, g_knob_def[i].name)) { g_knob[i] = value; return AV_OK; }
+    return av_set_error(AV_ERR_ARG, "set_knob: unknown knob '%s'", name);
+}
 const char* avllm_last_error(void) { return g_err; }
 int avllm_version(void) { return 100; }
 

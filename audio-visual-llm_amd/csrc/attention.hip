@@ -462,7 +462,7 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
         return av_attention_fwd_ref(q, k, v, o, lse, B, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, dtype, st, G);
     if (hd == 64) {
         // short non-causal self-attention (CLIP: 197 tokens, ViT-L/14: 257): whole-sequence scores in registers, exact two-pass softmax
-        static const bool short_off = getenv("AVLLM_ATTN_SHORT") && atoi(getenv("AVLLM_ATTN_SHORT")) == 0;
+        const bool short_off = av_knob(AV_KNOB_ATTN_SHORT) == 0;
         if (!causal && Tq == Tk && !short_off && B <= 65535) {
             if (Tq <= 208) return launch_fwd_short<13, 7>(q, k, v, o, lse, B, Tq, H, ldq, ldk, ldv, ldo, scale, st, G);
             if (Tq <= 272) return launch_fwd_short<17, 9>(q, k, v, o, lse, B, Tq, H, ldq, ldk, ldv, ldo, scale, st, G);

@@ -19,10 +19,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define AV_WAVE 64
 
-// A/B switches for tools/*_bench.py: read ONCE per process, at first use (never per layer or per launch).  Knobs that change what a
-// production kernel computes or stores (AVLLM_GEMM_DBG) exist only in builds made with -DAVLLM_EXPERIMENT_KNOBS.
-#define AV_ENV_INT(name, dflt) ([] { static const int v_ = getenv(name) ? atoi(getenv(name)) : (dflt); return v_; }())
-#define AV_ENV_SET(name) ([] { static const bool v_ = getenv(name) != nullptr; return v_; }())
+// A/B switches (tools/*_bench.py, the tests that compare two forms of one computation): ONE table in api.hip, filled once per process
+// from the environment (AVLLM_<NAME>) at first use and changed afterwards only through avllm_set_knob(name, value) -- never a getenv per
+// layer or per launch.  Knobs that change what a production kernel computes or stores (GEMM_DBG) exist only in builds made with
+// -DAVLLM_EXPERIMENT_KNOBS.
+enum AvKnob { AV_KNOB_DECODE_FUSED, AV_KNOB_DEC_AL, AV_KNOB_LORA_UNBATCHED, AV_KNOB_F8_UNFUSED_QUANT, AV_KNOB_F8_FAST, AV_KNOB_ATTN_SHORT,
+              AV_KNOB_NARROW_EPILOGUE, AV_KNOB_TN_CHUNK, AV_KNOB_GEMM_DBG, AV_KNOB_COUNT };
+int av_knob(int id);
 
 // ---- status / error string (thread local), SURVEY.md §8b "Errors" row
 #define AV_OK 0

@@ -35,6 +35,10 @@ struct DecArgs {
     const float* rope;                  // [hd/2][2] cos,sin of this position
     bf16* kc; bf16* vc;                 // cache of this layer [M(=B), Tmax, dkv]
     int Tmax, pos; const int* pos_dev;  // row written = pos (+ *pos_dev)
+    // LoRA side term (peft lora.Linear: + scale * B (A x)): lt [M, ldlt] f32 holds the rank-side products A x of this projection's input
+    // (columns 64 j .. 64 j + r of module j; made by a PLAIN launch over the A images), lb[j] the padded B image [rows, 64] of module j
+    // (QKV: j = q, k, v; otherwise j = 0).  Added in the epilogue, before RoPE.
+    const float* lt; long ldlt; const bf16* lb[3]; float lscale; int lr;
 };
 
 // fragment row fr (0..15) of workgroup b -> weight row, and the logical output column it produces
@@ -93,7 +97,7 @@ template <int J> __device__ __forceinline__ frag row_bcast(frag v) { return dpp4
 // The norm weights of the 4 steps come in ONE load (lane row fr & 3 holds step fr & 3) and reach all rows through a row broadcast.
 template <int AL, bool NORM> struct DecGrp { frag wb[4], xa[AL], gw; };
 
-template <bool NORM, int AL>
+template <bool NORM, int AL, bool LORA>
 __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
     __shared__ float part[DW][16][17];      // [wave][n][m]
     __shared__ float ssq[DW][16];
@@ -170,6 +174,26 @@ __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
         consume(gb, one);
         consume(ga, none);
     }
+    // adapters: the finishing thread (m, nn) fetches its 16 rank-side products and its B row now (the weight ring has drained; the loads
+    // fly while the partial tiles meet in LDS)
+    f32x4 ltv[4] = {};
+    bf16x8 lbv[2] = {};
+    if constexpr (LORA) {
+        if (threadIdx.x < 256 && (int)(threadIdx.x >> 4) < M) {
+            int oc;
+            dec_wrow(a, blockIdx.x, threadIdx.x & 15, oc);
+            int j = 0, row = oc;
+            if (a.mode == DEC_QKV) { j = oc < a.dq ? 0 : (oc < a.dq + a.dkv ? 1 : 2); row = oc - (j == 0 ? 0 : (j == 1 ? a.dq : a.dq + a.dkv)); }
+            if (oc < a.N) {
+                const float* tp = a.lt + (long)(threadIdx.x >> 4) * a.ldlt + 64 * j;
+                const bf16* bp2 = a.lb[j] + (long)row * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ltv[i] = *(const f32x4*)(tp + 4 * i);
+                lbv[0] = *(const bf16x8*)bp2;
+                lbv[1] = *(const bf16x8*)(bp2 + 8);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) part[w][fq * 4 + i][fr] = acc[i];
     if (NORM) {
@@ -188,6 +212,12 @@ __global__ __launch_bounds__(DW * 64, 2) void dec_proj_kernel(DecArgs a) {
 #pragma unroll
         for (int x = 0; x < DW; ++x) t += ssq[x][m];
         s *= rsqrtf(t / (float)a.K + a.eps);
+    }
+    if constexpr (LORA) {
+        float u = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u += (i < a.lr ? ltv[i >> 2][i & 3] : 0.f) * (float)lbv[i >> 3][i & 7];
+        s += a.lscale * u;
     }
     int ocol;
     dec_wrow(a, blockIdx.x, nn, ocol);
@@ -325,8 +355,12 @@ bool av_dec_proj_supported(int dtype, int M, int K, int N, int mode, int hd) {
 
 static int dec_launch(DecArgs& a, hipStream_t st) {
     const int grid = a.mode == DEC_SWIGLU ? a.N / 8 : a.N / 16;
-#define DEC_LAUNCH(NORMV, ALV) hipLaunchKernelGGL((dec_proj_kernel<NORMV, ALV>), dim3(grid), dim3(DW * 64), 0, st, a)
-    const int ev = AV_ENV_INT("AVLLM_DEC_AL", 0);       // experiment knob: force the activation-load form (4 = one load per step)
+#define DEC_LAUNCH(NORMV, ALV)                                                                                                   \
+    do {                                                                                                                       \
+        if (a.lt) hipLaunchKernelGGL((dec_proj_kernel<NORMV, ALV, true>), dim3(grid), dim3(DW * 64), 0, st, a);               \
+        else hipLaunchKernelGGL((dec_proj_kernel<NORMV, ALV, false>), dim3(grid), dim3(DW * 64), 0, st, a);                    \
+    } while (0)
+    const int ev = av_knob(AV_KNOB_DEC_AL);       // experiment knob: force the activation-load form (4 = one load per step)
     const int al = ev ? ev : (a.M <= 4 ? 1 : a.M <= 8 ? 2 : 4);
     if (a.norm_w) { if (al == 1 && a.M <= 4) DEC_LAUNCH(true, 1); else if (al <= 2 && a.M <= 8) DEC_LAUNCH(true, 2); else DEC_LAUNCH(true, 4); }
     else { if (al == 1 && a.M <= 4) DEC_LAUNCH(false, 1); else if (al <= 2 && a.M <= 8) DEC_LAUNCH(false, 2); else DEC_LAUNCH(false, 4); }
@@ -356,6 +390,15 @@ int av_dec_proj(const avllm_dec_proj_desc* d, hipStream_t st) {
         AV_CHECK_ARG(d->Tmax > 0 && d->pos >= 0 && (d->pos_dev || d->pos < d->Tmax), "dec_proj(q|k|v): pos=%d outside the cache (Tmax=%d)", d->pos, d->Tmax);
         a.dq = d->dq; a.dkv = d->dkv; a.hd = d->hd; a.rope = d->rope; a.kc = (bf16*)d->kc; a.vc = (bf16*)d->vc; a.Tmax = d->Tmax; a.pos = d->pos;
         a.pos_dev = d->pos_dev;
+    }
+    if (d->lora_t) {
+        const int nmod = d->mode == DEC_QKV ? 3 : 1;
+        AV_CHECK_ARG(d->mode != DEC_SWIGLU && d->lora_r > 0 && d->lora_r <= 16 && d->ld_lora_t >= 64 * nmod && d->ld_lora_t % 4 == 0 &&
+                     ((uintptr_t)d->lora_t & 15) == 0, "dec_proj: adapters need rank <= 16 (r=%d), 16-byte aligned rank-side products with >= %d columns per row",
+                     d->lora_r, 64 * nmod);
+        for (int j = 0; j < nmod; ++j) AV_CHECK_ARG(d->lora_b[j], "dec_proj: adapter B image %d missing", j);
+        a.lt = d->lora_t; a.ldlt = d->ld_lora_t; a.lscale = d->lora_scale; a.lr = d->lora_r;
+        for (int j = 0; j < nmod; ++j) a.lb[j] = (const bf16*)d->lora_b[j];
     }
     return dec_launch(a, st);
 }

@@ -62,7 +62,7 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
     for (int l = 0; l < layers; ++l) {
         const avllm_enc_layer& P = L[l];
         AV_CHECK_ARG(!fp8 || (P.wqkv8 && P.sqkv8 && P.wo8 && P.so8 && P.w18 && P.s18 && P.w28 && P.s28), "encoder layer %d: fp8 mode without fp8 weight images", l);
-        const bool nq = fp8 && d % 128 == 0 && d <= 8192 && !AV_ENV_SET("AVLLM_F8_UNFUSED_QUANT");      // LayerNorm straight to e4m3 + scales (fp8.hip norm_mxq_kernel)
+        const bool nq = fp8 && d % 128 == 0 && d <= 8192 && !av_knob(AV_KNOB_F8_UNFUSED_QUANT);      // LayerNorm straight to e4m3 + scales (fp8.hip norm_mxq_kernel)
         if (nq) AV_TRY(av_norm_mxq(b.x, P.ln1_w, P.ln1_b, nullptr, nullptr, b.f8.q, d, b.f8.s, M, d, eps, st));
         else AV_TRY(av_layernorm(b.x, P.ln1_w, P.ln1_b, b.xn, M, d, eps, dtype, st));
         avllm_gemm_desc g;
@@ -106,7 +106,7 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
                 F8Buf ffq;
                 ffq.q = b.ff; ffq.s = (char*)b.ff + (((size_t)M * ffn + 255) & ~(size_t)255);
                 q1.Cq = ffq.q; q1.SCq = ffq.s; q1.ldcq = ffn;
-                if (!AV_ENV_SET("AVLLM_F8_UNFUSED_QUANT") && avllm_gemm_f8_takes_quantised_output(&q1) && (size_t)M * ffn + 256 + avllm_mx_scale_bytes((int)M, ffn) <= (size_t)M * ffn * es) {
+                if (!av_knob(AV_KNOB_F8_UNFUSED_QUANT) && avllm_gemm_f8_takes_quantised_output(&q1) && (size_t)M * ffn + 256 + avllm_mx_scale_bytes((int)M, ffn) <= (size_t)M * ffn * es) {
                     AV_TRY(av_gemm_f8(&q1, st));
                     AV_TRY(f8_proj(ffq, (int)M, ffn, P.w28, P.s28, d, b.x, d, P.b2, AV_ACT_NONE, b.x, d, st));
                     continue;
@@ -383,7 +383,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
         }
         // all three rank-side products t_j = s * dropout_j(xn1) A_j^T in one launch (xn1 read once): csrc/lora_batch.hip
         const bool batch_qkv = !fp8 && dt == AV_BF16 && P.lora[0].A_pad && P.lora[1].A_pad && P.lora[2].A_pad && (!drop || fuse_drop) &&
-                               d % 256 == 0 && av_lora_batch_supported(dt, m->lora_r, 3) && !AV_ENV_SET("AVLLM_LORA_UNBATCHED");
+                               d % 256 == 0 && av_lora_batch_supported(dt, m->lora_r, 3) && !av_knob(AV_KNOB_LORA_UNBATCHED);
         if (batch_qkv) {
             const void* Ap[3] = {a.xn1, a.xn1, a.xn1}; const long la[3] = {d, d, d}; const int Kk[3] = {d, d, d};
             const void* Bp[3] = {P.lora[0].A_pad, P.lora[1].A_pad, P.lora[2].A_pad}; const long lb[3] = {d, d, d};
@@ -539,7 +539,7 @@ extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* 
         // ---- q,k,v projections (+LoRA)
         bool any = false, contiguous = true;
         const bool batch_bwd = dt == AV_BF16 && P.lora[0].A_pad && P.lora[1].A_pad && P.lora[2].A_pad && (!drop || fuse_drop) && d % 256 == 0 &&
-                               dkv % 256 == 0 && av_lora_batch_supported(dt, R, 3) && !AV_ENV_SET("AVLLM_LORA_UNBATCHED");
+                               dkv % 256 == 0 && av_lora_batch_supported(dt, R, 3) && !av_knob(AV_KNOB_LORA_UNBATCHED);
         if (batch_bwd) {      // three launches for the three adapters' dB, dt and dA (csrc/lora_batch.hip) instead of nine
             any = true;
             const void* Tq[3]; long ltq[3]; float* gBp[3]; long lgb[3]; int c0[3], nc[3];
@@ -612,7 +612,7 @@ extern "C" int avllm_llama_lora_bwd_layers(const avllm_llama* m, const int64_t* 
 
 // =============================================================================================== Llama inference
 namespace {
-struct LlamaInferWs { void *x, *xn, *qkv, *att, *t, *gu, *hmid, *logits; float* rope_tab; };
+struct LlamaInferWs { void *x, *xn, *qkv, *att, *t, *gu, *hmid, *logits; float* rope_tab; float* lt; };
 void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs& w, bool all_logits) {
     const size_t es = av_dtype_size(m->dtype);
     const long M = (long)B * S;
@@ -625,6 +625,7 @@ void carve_llama_infer(const avllm_llama* m, int B, int S, Bump& b, LlamaInferWs
     w.hmid = b.take((size_t)M * m->ffn * es);
     w.logits = b.take((size_t)(all_logits ? M : B) * m->vocab * 4);
     w.rope_tab = (float*)b.take((size_t)S * (m->d / m->heads) * 4);
+    w.lt = (float*)b.take((size_t)16 * 4 * AVLLM_LORA_PAD * 4);      // fused token step with adapters: rank-side products [B <= 16, 4 modules x 64] f32
 }
 
 // one decoder block on M = B*S rows at positions [pos0, pos0+S); K/V appended to the cache
@@ -699,17 +700,29 @@ extern "C" int avllm_llama_prefill(const avllm_llama* m, const void* x, int32_t 
     return AV_OK;
 }
 
-// One decoder block of a token step in 5 launches (decode.hip): bf16, B <= 16 sequences, no adapters on this layer.
+// One decoder block of a token step in 5 launches (decode.hip): bf16, B <= 16 sequences; 7 with adapters (rank <= 16: the rank-side
+// products of q|k|v and of o are two more -- tiny -- launches over the A images, the B side rides in the projections' epilogues).
+static bool llama_decode_lora_ok(const avllm_llama* m, const avllm_llama_layer& P, bool& any) {
+    int n = 0;
+    for (int j = 0; j < 4; ++j) n += P.lora[j].A_pad != nullptr;
+    any = n > 0;
+    if (n == 0) return true;
+    if (n != 4 || m->lora_r < 1 || m->lora_r > 16) return false;
+    for (int j = 0; j < 4; ++j) if (!P.lora[j].B_pad) return false;
+    // the A images of q, k, v must form one [3 x 64, d] matrix (avllm/engine.py allocates them that way): one launch makes all three products
+    const size_t step = (size_t)AVLLM_LORA_PAD * m->d * 2;
+    return (const char*)P.lora[1].A_pad == (const char*)P.lora[0].A_pad + step && (const char*)P.lora[2].A_pad == (const char*)P.lora[0].A_pad + 2 * step;
+}
 static bool llama_decode_fused_ok(const avllm_llama* m, int B) {
-    const bool off = AV_ENV_INT("AVLLM_DECODE_FUSED", 1) == 0;
+    const bool off = av_knob(AV_KNOB_DECODE_FUSED) == 0;
     if (off || m->dtype != AV_BF16 || B > 16) return false;
     const int hd = m->d / m->heads;
     if (!(hd == 64 || hd == 128)) return false;
     if (!av_dec_proj_supported(AV_BF16, B, m->d, llama_qw(m), 2, hd) || !av_dec_proj_supported(AV_BF16, B, m->d, m->ffn, 1, hd) ||
         !av_dec_proj_supported(AV_BF16, B, m->ffn, m->d, 0, hd) || !av_dec_proj_supported(AV_BF16, B, m->d, m->d, 0, hd)) return false;
+    bool any;
     for (int l = 0; l < m->layers; ++l)
-        for (int j = 0; j < 4; ++j)
-            if (m->layer[l].lora[j].A_pad) return false;          // adapters: the general path (lora_proj)
+        if (!llama_decode_lora_ok(m, m->layer[l], any)) return false;      // adapters the epilogue form does not cover: the general path (lora_proj)
     return true;
 }
 
@@ -719,13 +732,32 @@ static int llama_decode_layer_fused(const avllm_llama* m, int l, LlamaInferWs& w
     const int d = m->d, f = m->ffn, H = m->heads, hd = d / H, Hkv = llama_kv_heads(m), dkv = llama_dkv(m), qw = llama_qw(m);
     char* kcl = (char*)kc + (size_t)l * B * Tmax * dkv * 2;
     char* vcl = (char*)vc + (size_t)l * B * Tmax * dkv * 2;
+    bool lora = false;
+    llama_decode_lora_ok(m, P, lora);
+    constexpr int LT = 4 * AVLLM_LORA_PAD;
     avllm_dec_proj_desc p = {};
+    if (lora) {      // lora_A(rmsnorm(x)) of q, k, v in one launch over the stacked A images [3 x 64, d] -> lt[:, 0:192]
+        p.A = w.x; p.lda = d; p.W = P.lora[0].A_pad; p.ldw = d; p.norm_w = P.ln1_w; p.eps = m->eps; p.M = B; p.K = d; p.N = 3 * AVLLM_LORA_PAD; p.mode = 0;
+        p.C = w.lt; p.ldc = LT; p.out_f32 = 1;
+        AV_TRY(av_dec_proj(&p, st));
+        p = {};
+    }
     p.A = w.x; p.lda = d; p.W = P.wqkv; p.ldw = d; p.norm_w = P.ln1_w; p.eps = m->eps; p.M = B; p.K = d; p.N = qw; p.mode = 2;
     p.C = w.qkv; p.ldc = qw; p.dq = d; p.dkv = dkv; p.hd = hd; p.rope = w.rope_tab; p.kc = kcl; p.vc = vcl; p.Tmax = Tmax; p.pos = pos; p.pos_dev = pos_dev;
+    if (lora) {
+        p.lora_t = w.lt; p.ld_lora_t = LT; p.lora_r = m->lora_r; p.lora_scale = m->lora_scale;
+        for (int j = 0; j < 3; ++j) p.lora_b[j] = P.lora[j].B_pad;
+    }
     AV_TRY(av_dec_proj(&p, st));
     AV_TRY(av_attention_decode1(w.qkv, qw, kcl, vcl, w.att, d, B, H, hd, pos + 1, pos_dev, Tmax, 1.0f / sqrtf((float)hd), AV_BF16, st, H / Hkv));
     p = {};
+    if (lora) {      // lora_A(attention output) -> lt[:, 192:192+16]: only the rank's own 16 rows of the padded image are streamed
+        p.A = w.att; p.lda = d; p.W = P.lora[3].A_pad; p.ldw = d; p.M = B; p.K = d; p.N = 16; p.mode = 0; p.C = w.lt + 3 * AVLLM_LORA_PAD; p.ldc = LT; p.out_f32 = 1;
+        AV_TRY(av_dec_proj(&p, st));
+        p = {};
+    }
     p.A = w.att; p.lda = d; p.W = P.wo; p.ldw = d; p.M = B; p.K = d; p.N = d; p.mode = 0; p.C = w.x; p.ldc = d; p.R = w.x; p.ldr = d;
+    if (lora) { p.lora_t = w.lt + 3 * AVLLM_LORA_PAD; p.ld_lora_t = LT; p.lora_r = m->lora_r; p.lora_scale = m->lora_scale; p.lora_b[0] = P.lora[3].B_pad; }
     AV_TRY(av_dec_proj(&p, st));
     p = {};
     p.A = w.x; p.lda = d; p.W = P.wgu; p.ldw = d; p.norm_w = P.ln2_w; p.eps = m->eps; p.M = B; p.K = d; p.N = f; p.mode = 1; p.C = w.hmid; p.ldc = f;
@@ -756,7 +788,7 @@ extern "C" int avllm_llama_decode_step_at(const avllm_llama* m, const int64_t* i
             return av_dec_proj(&p, st);
         }
     } else {
-        AV_CHECK_ARG(!pos_dev, "llama_decode_step: a device-side position needs the fused bf16 token step (B <= 16, no adapters)");
+        AV_CHECK_ARG(!pos_dev, "llama_decode_step: a device-side position needs the fused bf16 token step (B <= 16, adapters of rank <= 16 or none)");
         for (int l = 0; l < m->layers; ++l) AV_TRY(llama_infer_layer(m, l, w, B, 1, pos, kcache, vcache, Tmax, st));
     }
     AV_TRY(av_rmsnorm_fwd(w.x, m->norm_w, w.xn, nullptr, B, d, m->eps, dt, st));
@@ -764,6 +796,8 @@ extern "C" int avllm_llama_decode_step_at(const avllm_llama* m, const int64_t* i
     g.out_f32 = 1;
     return av_gemm(&g, st);
 }
+
+extern "C" int avllm_llama_decode_is_fused(const avllm_llama* m, int32_t B) { return m && check_llama(m) == AV_OK && llama_decode_fused_ok(m, B) ? 1 : 0; }
 
 extern "C" int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, void* kcache,
                                        void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream) {

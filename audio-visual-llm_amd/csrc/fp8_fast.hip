@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
 static inline int f8_groups(int R) { return (R + 255) / 256 * 4; }      // mx_groups() of fp8.hip
 
 static bool f8_fast_takes(const avllm_gemm_f8_desc* d) {
-    static const int off = getenv("AVLLM_F8_FAST") ? atoi(getenv("AVLLM_F8_FAST")) == 0 : 0;
+    const int off = av_knob(AV_KNOB_F8_FAST) == 0;
     const int xtiles = av_cdiv(d->M, TM) * av_cdiv(d->N, TN);
     const bool aligned = (d->Cq || (uintptr_t)d->C % 16 == 0) && (!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->R || (uintptr_t)d->R % 16 == 0) && d->N % 8 == 0 &&
                          ((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0);
@@ -375,7 +375,7 @@ int av_gemm_f8_fast(const avllm_gemm_f8_desc* d, hipStream_t st, bool* taken) {
     g.A = (const uint8_t*)d->A; g.B = (const uint8_t*)d->B; g.SA = (const uint32_t*)d->SA; g.SB = (const uint32_t*)d->SB;
     g.lda = d->lda; g.ldb = d->ldb; g.K = d->K; g.RBA = f8_groups(d->M); g.RBB = f8_groups(d->N);
 #ifdef AVLLM_EXPERIMENT_KNOBS
-    g.dbg = AV_ENV_INT("AVLLM_GEMM_DBG", 0);
+    g.dbg = av_knob(AV_KNOB_GEMM_DBG);
 #else
     g.dbg = 0;
 #endif

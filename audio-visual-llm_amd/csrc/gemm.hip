@@ -1274,7 +1274,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
     const size_t osz = e.out_f32 ? 4 : 2;
     const bool wide_ok = d->dtype == AV_BF16 && d->N % 8 == 0 && ((uintptr_t)d->C % 16 == 0) && (d->ldc * osz) % 16 == 0 &&
                          (!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->R || ((uintptr_t)d->R % 16 == 0 && d->ldr % 8 == 0)) &&
-                         !AV_ENV_SET("AVLLM_NARROW_EPILOGUE");
+                         !av_knob(AV_KNOB_NARROW_EPILOGUE);
     if (d->dtype == AV_BF16 && d->M <= 16 && d->N % 16 == 0 && d->K % (32 * SK_WAVES) == 0 && d->K2 % 32 == 0 && d->g_in == 0 &&
         d->drop_p <= 0.f && d->a_drop_p <= 0.f && g_gemm_variant <= 0) {      // a_drop: the rank-side kernel below owns the fused mask
         GemmArgs g;
@@ -1307,7 +1307,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
         g.wide_epi = wide_ok;
 #ifdef AVLLM_EXPERIMENT_KNOBS
-        g.dbg = AV_ENV_INT("AVLLM_GEMM_DBG", 0);
+        g.dbg = av_knob(AV_KNOB_GEMM_DBG);
 #else
         g.dbg = 0;
 #endif

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16* __restric
 int av_gemm_tn_mfma(const void* Big, long ldb, int NB, const void* Small, long lds_, int R, int M, float* out, long ldo, float alpha,
                     int trans_out, hipStream_t st, uint32_t drop_seed, float drop_p, const uint32_t* seed_dev) {
     // token chunks: enough workgroups to fill the chip (NB/128 x zs >= 256) but as few atomic adders per element as that allows
-    static const int chunk_env = getenv("AVLLM_TN_CHUNK") ? atoi(getenv("AVLLM_TN_CHUNK")) : 0;
+    const int chunk_env = av_knob(AV_KNOB_TN_CHUNK);
     // [NB,R] output = 64-byte rows scattered across lanes (slow atomics): fewer, longer chunks (measured 13.8 vs 18.3 us at 512 vs 256)
     const int want = chunk_env > 0 ? chunk_env : (trans_out ? 256 : 512);
     int zs = av_cdiv(M, want);

@@ -177,6 +177,55 @@ def host_inputs_leg(args, cfg, model, trainer, labels, prompt, dev, rank, world,
                     "avllm_logmel (f32) + avllm_clip_preproc (bf16 pixel_values) into the captured step's input buffers -> train step"}
 
 
+def config5_leg(dev, steps=4, B=4, frames=750):
+    """BASELINE configs[4] as a driver-timed variant: Whisper-large-v3 (128 mel bins, 32 x d1280) + CLIP ViT-L/14 (257 tokens per frame) ->
+    Mistral-7B (grouped-query) with LoRA, 30 s utterances (750 frames), B clips per step, full train step.  ONE model built with
+    precision="fp8" (bf16 weights + e4m3 images) runs the step in both arithmetics: fp8 = the frozen forward projections on the block-scaled
+    fp8 matrix pipe, bf16 = the same launches with the engines' fp8 flag off.  Each: 2 warm-up steps (the second captures the hipGraph),
+    `steps` replayed steps timed with a device sync on both sides, then one eager step with every GEMM launch bracketed by HIP events."""
+    from avllm import lib as L
+    from avllm.model import ClipWhisperModel
+    from avllm.trainer import ClipWhisperTrainer
+    lib = L.load()
+    model = ClipWhisperModel("mistralai/Mistral-7B-v0.1", "openai/whisper-large-v3", "openai/clip-vit-large-patch14", device=dev, max_seq_len=512,
+                             precision="fp8", seed=0, synthetic_weights=True).train()
+    cfg = model.cfg
+    batch = synthetic_batch(cfg, B, frames, 4321, dev)
+    engines = [model.whisper_engine, model.clip_engine, model.llm_engine]
+    out = {"workload": f"BASELINE configs[4]: whisper-large-v3 + clip-vit-large-patch14 -> Mistral-7B lora r16, synthetic {frames / 25:g} s clips ({frames} frames), "
+                       f"per_gpu_batch {B}, max_seq_len 512, train seq 256", "steps": steps, "warmup": 2}
+    for mode in ("bf16", "fp8"):
+        for e in engines:
+            e.desc.fp8 = int(mode == "fp8")
+        tr = ClipWhisperTrainer(model, learning_rate=5e-5, weight_decay=0.01, grad_clip=0.5, total_steps=1000, use_graph=True)
+        for _ in range(2):
+            tr.train_step(*batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.train_step(*batch)
+        torch.cuda.synchronize()
+        ms = 1000 * (time.perf_counter() - t0) / steps
+        prof = (ctypes.c_double * 4)()
+        L.check(lib.avllm_profile_begin(8000))
+        L.check(lib.avllm_profile_enable(1))
+        tr.train_step(*batch, graph=False)
+        torch.cuda.synchronize()
+        L.check(lib.avllm_profile_end(prof))
+        peak = MFMA_FP8_PEAK if mode == "fp8" else MFMA_BF16_PEAK
+        ach = prof[1] / (prof[0] * 1e-3) / 1e12 if prof[0] > 0 else 0.0
+        out[mode] = {"ms_per_step": round(ms, 3), "samples_per_s": round(B * 1000 / ms, 4), "final_loss": round(float(loss), 5),
+                     "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4),
+                                  "gemm_ms_per_step": round(prof[0], 3), "gemm_tflop_per_step": round(prof[1] / 1e12, 3), "launches_per_step": int(prof[2]),
+                                  "note": "every avllm_gemm / avllm_gemm_f8 launch of one eager step, HIP events on the launching stream; fp8 is priced "
+                                          "against the 5 PF/s fp8 peak although its backward dX and LoRA GEMMs run in bf16"}}
+        del tr
+    out["fp8_speedup_vs_bf16"] = round(out["bf16"]["ms_per_step"] / out["fp8"]["ms_per_step"], 4)
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +243,7 @@ def main():
                     "frame counts (~6 s; reads ~1.3x faster than the full step)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the second leg (batches arriving in pinned host memory as raw uint8 frames + samples)")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the variants.config5_fp8 leg (BASELINE configs[4] in fp8 and bf16, B=4 x 750 frames)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
@@ -296,6 +346,12 @@ def main():
     decode_leg = None
     if rank == 0 and world == 1 and not args.no_decode and not args.tiny:
         decode_leg = decode_bench(model, cfg, args, dev)
+    variants = None
+    if rank == 0 and world == 1 and not args.no_config5 and not args.tiny and default_llm and args.precision == "bf16":
+        # the main model's step graphs and activations go first: the variant is another 7B model with 30 s batches
+        trainer._graphs = {}
+        torch.cuda.empty_cache()
+        variants = {"config5_fp8": config5_leg(dev)}
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
@@ -314,6 +370,8 @@ def main():
             out["config"]["host_inputs"] = host_leg
         if decode_leg is not None:
             out["decode"] = decode_leg
+        if variants is not None:
+            out["variants"] = variants
         frac_e2e = value / world * FLOP_PER_CLIP / MFMA_BF16_PEAK
         peak = MFMA_FP8_PEAK if args.precision == "fp8" else MFMA_BF16_PEAK
         if timing and prof[2] > 0:

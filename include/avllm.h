@@ -61,6 +61,12 @@ typedef struct avllm_gemm_desc {
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
 /* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT) */
 int avllm_set_gemm_variant(int v);
+/* A/B testing only: the library's experiment switches live in ONE table that is filled once per process from the environment
+ * (AVLLM_<NAME>) and changed afterwards only through this call.  Names: "DECODE_FUSED" (0 = general 10-launch decode layer),
+ * "DEC_AL" (force an activation-load form of avllm_dec_proj: 2 | 4), "LORA_UNBATCHED" (1 = one launch per adapter), "F8_UNFUSED_QUANT"
+ * (1 = separate quantiser passes), "F8_FAST" (0 = reference-grade fp8 GEMM), "ATTN_SHORT" (0 = general attention kernel for T <= 272),
+ * "NARROW_EPILOGUE", "TN_CHUNK", "GEMM_DBG" (only read by builds made with -DAVLLM_EXPERIMENT_KNOBS).  Unknown name -> error. */
+int avllm_set_knob(const char* name, int32_t value);
 
 /* out[I,J] (f32, row stride ldo) += alpha * sum_m P[m,i]*Q[m,j]; LoRA dA/dB (autograd of peft lora.Linear) */
 int avllm_gemm_tn(const void* P, int64_t ldp, int32_t I, const void* Q, int64_t ldq, int32_t J, int32_t M,
@@ -395,6 +401,9 @@ int avllm_llama_decode_step(const avllm_llama* m, const int64_t* ids, int32_t B,
  * avllm_pos_advance).  The caller guarantees pos + *pos_dev < Tmax. */
 int avllm_llama_decode_step_at(const avllm_llama* m, const int64_t* ids, int32_t B, int32_t pos, const int32_t* pos_dev, void* kcache,
                                void* vcache, int32_t Tmax, float* logits, void* ws, size_t ws_bytes, void* stream);
+/* 1 when a token step of B sequences on this model takes the fused bf16 path (one launch per projection + one attention launch per
+ * layer), 0 when it takes the general path: tests and benchmarks assert which one they measured. */
+int avllm_llama_decode_is_fused(const avllm_llama* m, int32_t B);
 int avllm_pos_advance(int32_t* pos_dev, int32_t by, void* stream);
 
 /* One projection of a decode token step (bf16, 1 <= M <= 16 rows, K % 128 == 0): C = epilogue(rmsnorm?(A) . W^T).  Every weight row
@@ -416,6 +425,13 @@ typedef struct avllm_dec_proj_desc {
     void *kc, *vc;
     int32_t Tmax, pos;
     const int32_t* pos_dev;
+    /* LoRA side term of peft lora.Linear, + lora_scale * B (A x), added in the epilogue (before RoPE): lora_t [M, ld_lora_t] f32 holds the
+     * rank-side products of this projection's (normalised) input, module j in columns [64 j, 64 j + lora_r) -- itself a mode-0 launch over
+     * the A images; lora_b[j] = padded B image [rows of module j, 64] (avllm_lora_pack).  mode 2: j = q, k, v; mode 0: j = 0; not with mode 1.
+     * lora_t == NULL: no adapters. */
+    const float* lora_t; int64_t ld_lora_t;
+    const void* lora_b[3];
+    int32_t lora_r; float lora_scale;
 } avllm_dec_proj_desc;
 int avllm_dec_proj(const avllm_dec_proj_desc* d, void* stream);
 /* Single-query attention over the cache rows [0, Tk + *tk_dev) (tk_dev may be NULL) of kc/vc [B][Tmax][(H/kv_group)*hd]: one pass with

@@ -358,10 +358,12 @@ def train_step_grads(W, cfg, audio, video, prompt, labels, masks=None):
     return loss.detach(), logits.detach(), {k: v.grad for k, v in lora.items()}
 
 
-def generate(W, cfg, audio=None, video=None, prompt=None, max_new_tokens=100, eos_token_id=None):
+def generate(W, cfg, audio=None, video=None, prompt=None, max_new_tokens=100, eos_token_id=None, return_margins=False):
     """ClipWhisperModel.generate, clip_whisper_model.py:1240-1348 -> HF GenerationMixin greedy search
     (do_sample=False) on inputs_embeds with a KV cache; returns new tokens only [B, <=max_new_tokens].
-    After a row emits eos it is padded with pad_token_id (HF greedy `unfinished_sequences` rule)."""
+    After a row emits eos it is padded with pad_token_id (HF greedy `unfinished_sequences` rule).
+    return_margins: also return the top-1 minus top-2 logit of every step [B, steps] (a reduced-precision implementation can only be
+    held to the same token where this margin exceeds its logit error; tests/test_decode_gpu.py)."""
     with torch.no_grad():
         x, mask = encode(W, cfg, audio, video, prompt)
         sd, c = W["llama"], cfg.llama
@@ -370,10 +372,12 @@ def generate(W, cfg, audio=None, video=None, prompt=None, max_new_tokens=100, eo
         pos = x.shape[1]
         B = x.shape[0]
         unfinished = torch.ones(B, dtype=torch.bool)
-        out = []
+        out, margins = [], []
         for _ in range(max_new_tokens):
             logits = h[:, -1] @ sd["lm_head.weight"].T
             nxt = logits.argmax(-1)
+            top2 = logits.topk(2, dim=-1).values
+            margins.append(top2[:, 0] - top2[:, 1])
             if eos_token_id is not None:
                 nxt = torch.where(unfinished, nxt, torch.full_like(nxt, cfg.pad_token_id))
                 unfinished = unfinished & (nxt != eos_token_id)
@@ -382,6 +386,8 @@ def generate(W, cfg, audio=None, video=None, prompt=None, max_new_tokens=100, eo
                 break
             h = llama_hidden(sd, W.get("lora"), c, cfg.lora, sd["model.embed_tokens.weight"][nxt][:, None], past=past, pos0=pos)
             pos += 1
+        if return_margins:
+            return torch.stack(out, dim=1), torch.stack(margins, dim=1)
         return torch.stack(out, dim=1)
 
 

@@ -84,28 +84,34 @@ def run(cfg: Wt.ModelCfg | None = None, frames: int = 125, sample_frames: int = 
     }
 
 
-def run_full(cfg: Wt.ModelCfg | None = None, frames: int = 125, threads: int | None = None):
-    """ONE complete B=1 train step of the oracle at full depth and width (BASELINE.md §2 protocol, minus the optimizer's microseconds):
-    every encoder layer, every frame, all decoder layers forward and backward.  The 32 decoder layers share ONE set of random tensors
-    (same arithmetic and cache behaviour per layer, 1/32 of the 27 GB an fp32 Llama-2-7B would need on the host)."""
-    cfg = cfg or Wt.config2()
-    threads = threads or min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    t_all = time.time()
+def shared_depth_weights(cfg: Wt.ModelCfg, seed: int = 0, lora_b_std: float = 0.01, distinct_lora: bool = False):
+    """Weights of the full-depth model with the decoder layers sharing ONE set of frozen tensors (same arithmetic and cache behaviour per
+    layer, 1/layers of the 27 GB an fp32 Llama-2-7B would need on the host).  The adapters are per layer: copies of one draw, or -- with
+    `distinct_lora` -- independent draws (tests/test_pin_bf16_gpu.py's full-depth pin)."""
     one = Wt.LlamaCfg(**{**vars(cfg.llama), "layers": 1})
-    L1 = Wt.llama_weights(one, 0)
+    L1 = Wt.llama_weights(one, seed)
     llama = {k: v for k, v in L1.items() if "layers." not in k}
-    lora1 = Wt.lora_weights(one, cfg.lora, 0, 0.01)
     lora = {}
     for i in range(cfg.llama.layers):
         for k, v in L1.items():
             if k.startswith("model.layers.0."):
                 llama[k.replace("model.layers.0.", f"model.layers.{i}.")] = v
-        for k, v in lora1.items():
+        for k, v in Wt.lora_weights(one, cfg.lora, seed + (i if distinct_lora else 0), lora_b_std).items():
             lora[k.replace("layers.0.", f"layers.{i}.")] = v.clone()
-    W = {"whisper": Wt.whisper_weights(cfg.whisper, 0), "clip": Wt.clip_weights(cfg.clip, 0), "llama": llama, "lora": lora,
-         "audio_connector": Wt.connector_weights(cfg.whisper.d_model, cfg.llama.hidden, "conn.audio", 0),
-         "video_connector": Wt.connector_weights(cfg.clip.hidden, cfg.llama.hidden, "conn.video", 0)}
+    return {"whisper": Wt.whisper_weights(cfg.whisper, seed), "clip": Wt.clip_weights(cfg.clip, seed), "llama": llama, "lora": lora,
+            "audio_connector": Wt.connector_weights(cfg.whisper.d_model, cfg.llama.hidden, "conn.audio", seed),
+            "video_connector": Wt.connector_weights(cfg.clip.hidden, cfg.llama.hidden, "conn.video", seed)}
+
+
+def run_full(cfg: Wt.ModelCfg | None = None, frames: int = 125, threads: int | None = None):
+    """ONE complete B=1 train step of the oracle at full depth and width (BASELINE.md §2 protocol, minus the optimizer's microseconds):
+    every encoder layer, every frame, all decoder layers forward and backward.  The 32 decoder layers share ONE set of random tensors
+    (shared_depth_weights)."""
+    cfg = cfg or Wt.config2()
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    t_all = time.time()
+    W = shared_depth_weights(cfg)
     audio, video, labels, prompt = Wt.synthetic_batch(cfg, 1, frames, seed=1234)
     t_setup = time.time() - t_all
     split = {}

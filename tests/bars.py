@@ -49,6 +49,30 @@ FP8_LOSS_ABS = 6e-2
 FP8_GRAD_REL_L2 = 1.5e-1
 FP8_ENC_REL_L2 = 6e-2
 FP8_VS_UNQUANTISED_REL_L2 = 2.5e-1
+# At realistic widths (K >= 1024: tests/test_fp8_gpu.py's config-5 family test) a flipped e4m3 rounding decision is averaged over 8x more
+# products, so the fp8 path is held to 2x the bf16 bars against the fake-quantised oracle.
+FP8_WIDE_LOGITS_REL_L2 = 2 * BF16_LOGITS_REL_L2
+FP8_WIDE_LOSS_ABS = 2 * BF16_LOSS_ABS
+FP8_WIDE_GRAD_REL_L2 = 2 * BF16_GRAD_REL_L2
+FP8_WIDE_ENC_REL_L2 = 2 * BF16_ENC_REL_L2
+
+
+# ---- bf16 at depth (tests/test_pin_bf16_gpu.py full-depth pin): the same derivation evaluated at the depth the bench runs instead of
+# the <= 2 layers above.  Forward: u/sqrt(3) * sqrt(8 L) relative L2 on the hidden state (and the logits, a linear map of it); backward and
+# LoRA gradients ~2x that (see above); the loss is a mean over ~30 scored tokens of log-probabilities whose logits carry that error.
+BF16_DEPTH_FACTOR = 3.0          # bar = this x the estimate (the <= 2-layer bars above use 4x; at depth the estimate itself is larger)
+
+
+def bf16_depth_rel_l2(layers, per_layer_roundings=8):
+    return BF16_DEPTH_FACTOR * 1.13e-3 * (per_layer_roundings * layers) ** 0.5
+
+
+def bf16_depth_grad_rel_l2(layers):
+    return 2.0 * bf16_depth_rel_l2(layers)
+
+
+def bf16_depth_loss_abs(layers):
+    return BF16_LOSS_ABS * (layers / 2.0) ** 0.5
 
 
 def rel_l2(a, b):

@@ -68,7 +68,7 @@ def test_persistent_gemm_k_loop_has_no_compiler_waits_or_spills(tmp_path):
 def test_decode_ring_registers_are_not_copied_in_flight(tmp_path):
     asm = _asm(os.path.join(ROOT, "audio-visual-llm_amd", "csrc", "decode.hip"), tmp_path)
     kernels = _kernel(asm, r"dec_proj_kernel")
-    assert len(kernels) == 6
+    assert len(kernels) == 12                                     # NORM x 3 activation-load forms x adapters in the epilogue or not
     for name, lines in kernels.items():
         loops = _inner_loops(lines)
         assert loops, name

@@ -47,11 +47,8 @@ def test_dec_proj_activation_load_forms(dev, M, al):
     A, W = rnd(M, K, dtype=BF, seed=1), rnd(528, K, dtype=BF, seed=2, scale=K ** -0.5)
     g = (1.0 + 0.1 * rnd(K, dtype=torch.float32, seed=4)).to(BF)
     want = ops.dec_proj(A, W, out_f32=True), ops.dec_proj(A, W, norm_w=g, eps=1e-5, out_f32=True)
-    os.environ["AVLLM_DEC_AL"] = al
-    try:
+    with ops.L.knob("DEC_AL", int(al)):
         got = ops.dec_proj(A, W, out_f32=True), ops.dec_proj(A, W, norm_w=g, eps=1e-5, out_f32=True)
-    finally:
-        os.environ.pop("AVLLM_DEC_AL", None)
     assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
     assert rel_l2(want[1], rms(A, g, 1e-5) @ W.float().t()) < 6e-3
 
@@ -93,6 +90,62 @@ def test_dec_proj_qkv_rope_cache(dev, M, heads, kvh, hd, K):
         assert rel_l2(vc[:, pos], y[:, dq + dkv:]) < 8e-3
         keep = [t for t in range(Tmax) if t != pos]
         assert (kc[:, keep] == 7.0).all() and (vc[:, keep] == -7.0).all()
+
+
+@pytest.mark.parametrize("M,r", [(1, 16), (5, 8), (8, 16), (16, 4)])
+def test_dec_proj_adapter_side_term_plain_and_qkv(dev, M, r):
+    """peft lora.Linear on the fused token step: y = W x + scale * B (A x).  The rank-side products A x come from a mode-0 launch over the
+    padded A images (f32 out), the B side rides in the projection's epilogue -- BEFORE RoPE in the q|k|v form.  Against fp32 torch on the
+    same bf16 operands; a wrong module offset, a missing scale or a term added after the rotation each miss the bar by far."""
+    K, scale = 1152, 2.0
+    g = (1.0 + 0.1 * rnd(K, dtype=torch.float32, seed=43)).to(BF)
+    A = rnd(M, K, dtype=BF, seed=41)
+    # ---- plain (o_proj form: no norm, residual)
+    N = 528
+    W = rnd(N, K, dtype=BF, seed=42, scale=K ** -0.5)
+    Ap = torch.zeros(64, K, device=dev, dtype=BF); Ap[:r] = rnd(r, K, dtype=BF, seed=44, scale=K ** -0.5)
+    Bp = torch.zeros(N, 64, device=dev, dtype=BF); Bp[:, :r] = rnd(N, r, dtype=BF, seed=45, scale=0.3)
+    R = rnd(M, N, dtype=BF, seed=46)
+    t = torch.zeros(M, 256, device=dev, dtype=torch.float32)
+    ops.dec_proj(A, Ap[:16], out=t[:, 192:208], out_f32=True)
+    ref_t = A.float() @ Ap[:16].float().t()
+    assert rel_l2(t[:, 192:208], ref_t) < 2e-3
+    out = ops.dec_proj(A, W, R=R, lora_t=t[:, 192:], lora_b=[Bp], lora_r=r, lora_scale=scale, out_f32=True)
+    ref = A.float() @ W.float().t() + R.float() + scale * (ref_t[:, :r] @ Bp[:, :r].float().t())
+    assert rel_l2(out, ref) < 3e-3
+    assert rel_l2(ops.dec_proj(A, W, R=R, out_f32=True), ref) > 0.05              # the side term is not small here
+    # ---- q|k|v with norm + RoPE + cache (grouped-query widths)
+    heads, kvh, hd, Tmax, pos = 4, 2, 64, 6, 3
+    dq, dkv = heads * hd, kvh * hd
+    Wq = rnd(dq + 2 * dkv, K, dtype=BF, seed=47, scale=K ** -0.5)
+    A3 = torch.zeros(192, K, device=dev, dtype=BF)
+    Bs = []
+    for j, rows in enumerate((dq, dkv, dkv)):
+        A3[64 * j:64 * j + r] = rnd(r, K, dtype=BF, seed=50 + j, scale=K ** -0.5)
+        b = torch.zeros(rows, 64, device=dev, dtype=BF); b[:, :r] = rnd(rows, r, dtype=BF, seed=60 + j, scale=0.3)
+        Bs.append(b)
+    ops.dec_proj(A, A3, norm_w=g, eps=1e-5, out=t[:, :192], out_f32=True)
+    xn = rms(A, g, 1e-5)
+    y = xn @ Wq.float().t()
+    off = 0
+    for j, rows in enumerate((dq, dkv, dkv)):
+        y[:, off:off + rows] += scale * ((xn @ A3[64 * j:64 * j + r].float().t()) @ Bs[j][:, :r].float().t())
+        off += rows
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    ang = pos * inv
+    rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+
+    def rot(t_, nh):
+        t_ = t_.view(M, nh, hd)
+        a, b = t_[..., : hd // 2], t_[..., hd // 2:]
+        return torch.cat([a * ang.cos() - b * ang.sin(), b * ang.cos() + a * ang.sin()], -1).reshape(M, nh * hd)
+
+    kc = torch.zeros(M, Tmax, dkv, device=dev, dtype=BF); vc = torch.zeros_like(kc)
+    q = ops.dec_proj(A, Wq, mode=2, norm_w=g, eps=1e-5, rope=rope, kc=kc, vc=vc, pos=pos, dq=dq, dkv=dkv, hd=hd,
+                     lora_t=t, lora_b=Bs, lora_r=r, lora_scale=scale)
+    assert rel_l2(q, rot(y[:, :dq], heads)) < 8e-3
+    assert rel_l2(kc[:, pos], rot(y[:, dq:dq + dkv], kvh)) < 8e-3
+    assert rel_l2(vc[:, pos], y[:, dq + dkv:]) < 8e-3
 
 
 def test_dec_proj_refuses_what_it_cannot_do(dev):
@@ -159,8 +212,7 @@ def test_token_step_fused_matches_general_path_and_prefill(dev, hidden, heads, k
     ref_all = eng.prefill(x, *eng.alloc_cache(B, S + new), all_logits=True)[1].float()      # [B, S+new, vocab]: teacher-forced logits
 
     def run(fused, device_pos):
-        os.environ["AVLLM_DECODE_FUSED"] = "1" if fused else "0"
-        try:
+        with ops.L.knob("DECODE_FUSED", 1 if fused else 0):
             kc, vc = eng.alloc_cache(B, S + new + 2)
             eng.prefill(x[:, :S].contiguous(), kc, vc)
             pd = torch.zeros(1, device=dev, dtype=torch.int32) if device_pos else None
@@ -172,8 +224,6 @@ def test_token_step_fused_matches_general_path_and_prefill(dev, hidden, heads, k
                 else:
                     outs.append(eng.decode_step(ids[:, S + t].contiguous(), S + t, kc, vc).clone())
             return torch.stack(outs, 1)
-        finally:
-            os.environ.pop("AVLLM_DECODE_FUSED", None)
 
     general, fused, fused_dev = run(False, False), run(True, False), run(True, True)
     want = ref_all[:, S:S + new]
@@ -181,9 +231,44 @@ def test_token_step_fused_matches_general_path_and_prefill(dev, hidden, heads, k
     assert rel_l2(fused, want) < BF16_LOGITS_REL_L2
     assert rel_l2(fused, general) < BF16_LOGITS_REL_L2
     assert torch.equal(fused, fused_dev)                          # same kernels, the position merely comes from memory
-    with pytest.raises(ValueError):
-        os.environ["AVLLM_DECODE_FUSED"] = "0"
-        try:
-            eng.decode_step(ids[:, 0].contiguous(), 1, *eng.alloc_cache(B, 4), pos_dev=torch.zeros(1, device=dev, dtype=torch.int32))
-        finally:
-            os.environ.pop("AVLLM_DECODE_FUSED", None)
+    with pytest.raises(ValueError), ops.L.knob("DECODE_FUSED", 0):
+        eng.decode_step(ids[:, 0].contiguous(), 1, *eng.alloc_cache(B, 4), pos_dev=torch.zeros(1, device=dev, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("with_lora", [False, True])
+def test_generate_bf16_fused_token_step_vs_oracle_greedy(dev, golden_dir, with_lora):
+    """generate() in bf16 -- the arithmetic bench.py's decode{} times: prefill + the fused token step (asserted: avllm_llama_decode_is_fused) --
+    against the ORACLE's greedy search on the reference-pinned tiny model (clip_whisper_model.py:1337-1340 -> HF greedy).  bf16 cannot promise
+    the fp32 token where the top-2 logits are closer than its own logit error, so each row is compared up to (not including) the first step
+    whose oracle margin is below 2 x the bf16 logit bar; from there on the two searches may legitimately walk different paths.  With and
+    without adapters (decode.py runs without; the trainer's eval and `decode.py --load_lora` with)."""
+    import numpy as np
+    from bars import BF16_LOGIT_MAX_ABS
+    from oracle import avsr_oracle as O
+    from oracle import weights as Wt
+    from test_model_gpu import make_model
+    g = np.load(f"{golden_dir}/g2_tiny_e2e.npz")
+    oc = Wt.tiny()
+    W = Wt.all_weights(oc, int(g["seed"]), lora_b_std=0.05)
+    if not with_lora:
+        W = {k: v for k, v in W.items() if k != "lora"}
+    audio, video, _, _ = Wt.synthetic_batch(oc, 2, int(g["frames"]), seed=int(g["batch_seed"]))
+    new = 16
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
+    m = ClipWhisperModel(device="cuda:0", use_lora=with_lora, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=256, config=cfg,
+                         weights=W, precision="bf16").eval()
+    assert m.llm_engine.decode_is_fused(2), "the fused token step must take this model (bf16, B <= 16" + (", adapters" if with_lora else "") + ")"
+    ids = m.generate(audio=audio.to(dev), video=video.to(dev), max_new_tokens=new).cpu()
+    oc.max_seq_len = 256
+    ref, margins = O.generate(W, oc, audio, video, None, max_new_tokens=new, eos_token_id=m.eos_token_id, return_margins=True)
+    thr = 2.0 * BF16_LOGIT_MAX_ABS
+    compared = 0
+    for b in range(ref.shape[0]):
+        for t in range(min(ref.shape[1], ids.shape[1])):
+            if float(margins[b, t]) < thr:
+                break
+            assert int(ids[b, t]) == int(ref[b, t]), (b, t, ids[b].tolist(), ref[b].tolist(), margins[b].tolist())
+            compared += 1
+    assert compared >= 8, (compared, margins.tolist())           # not vacuous: at least 8 tokens were held to the oracle's choice

@@ -95,9 +95,9 @@ def test_batched_and_unbatched_steps_agree(dev, monkeypatch):
     video = torch.randn(2, 7, 3, 48, 48, generator=g, device=dev)
     labels = torch.randint(3, 256, (2, 40), generator=g, device=dev)
     res = {}
+    from avllm import lib as Lk
     for mode in ("batched", "unbatched"):
-        if mode == "unbatched":
-            monkeypatch.setenv("AVLLM_LORA_UNBATCHED", "1")
+        Lk.check(Lk.load().avllm_set_knob(b"LORA_UNBATCHED", 1 if mode == "unbatched" else 0))
         m = ClipWhisperModel(device=dev, max_seq_len=64, config=cfg, precision="bf16", seed=3, synthetic_weights=True, lora_dropout=0.1).train()
         eng = m.llm_engine
         eng.lora_p.normal_(0, 0.02, generator=g.manual_seed(9))
@@ -105,6 +105,7 @@ def test_batched_and_unbatched_steps_agree(dev, monkeypatch):
         out = m(audio=audio, video=video, labels=labels)
         out["loss"].backward()
         res[mode] = (float(out["loss"].detach()), eng.lora_g.clone())
+    Lk.check(Lk.load().avllm_set_knob(b"LORA_UNBATCHED", 0))
     assert abs(res["batched"][0] - res["unbatched"][0]) < 1e-6
     assert rel_l2(res["batched"][1], res["unbatched"][1]) < 1e-4
     assert float(res["batched"][1].abs().max()) > 0
