@@ -124,6 +124,7 @@ _SIGS = {
     "avllm_clip_cls_rows": ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "avllm_fuse_pool": ([vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     "avllm_grad_sumsq": ([vp, i64, vp, vp], i32),
+    "avllm_grad_sumsq_det": ([vp, i64, vp, i32, vp, vp], i32),
     "avllm_adamw_step": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp, vp, vp, vp], i32),
     "avllm_step_advance": ([vp, C.POINTER(Schedule), vp], i32),
     "avllm_mx_scale_bytes": ([i32, i32], sz),

@@ -193,7 +193,11 @@ def fuse_pool(a, v, prompt_emb, L_, S_out, fusion_scale, D, B):
     return out
 
 
-def grad_sumsq(g, out):
+def grad_sumsq(g, out, partials=None):
+    """out += sum g^2 (float atomics), or -- with a `partials` scratch tensor (float32, <= 1024 used) -- out = sum g^2 in a fixed order."""
+    if partials is not None:
+        L.check(L.load().avllm_grad_sumsq_det(L.ptr(g), g.numel(), L.ptr(partials), partials.numel(), L.ptr(out), L.stream_ptr()))
+        return
     L.check(L.load().avllm_grad_sumsq(L.ptr(g), g.numel(), L.ptr(out), L.stream_ptr()))
 
 

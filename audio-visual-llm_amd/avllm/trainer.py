@@ -50,6 +50,7 @@ class ClipWhisperTrainer:
         self.m = torch.zeros_like(eng.lora_p)
         self.v = torch.zeros_like(eng.lora_p)
         self.sumsq = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)
+        self._sumsq_parts = torch.zeros(1024, device=eng.lora_p.device, dtype=torch.float32)      # fixed-order gradient norm: replicas stay bit-identical
         self.skipped = torch.zeros(1, device=eng.lora_p.device, dtype=torch.float32)      # optimizer steps skipped on a non-finite loss / gradient
         self.reducer = LoraGradReducer(eng.lora_g, eng.per_layer, eng.cfg.layers)
         dev = eng.lora_p.device
@@ -120,8 +121,7 @@ class ClipWhisperTrainer:
 
     def _part_opt(self):
         eng = self.model.llm_engine
-        self.sumsq.zero_()
-        ops.grad_sumsq(eng.lora_g, self.sumsq)
+        ops.grad_sumsq(eng.lora_g, self.sumsq, partials=self._sumsq_parts)
         # NaN/Inf guard of trainer :444-452 without a host sync: a non-finite (all-reduced) loss sum or gradient norm makes the update a
         # no-op on every rank alike (the all-reduce spreads the NaN), leaving lora_p, m and v untouched; `skipped_steps` counts them and
         # the device-side step count goes back by one, so neither the LR schedule nor Adam's bias corrections advance (as in the reference,

@@ -88,6 +88,7 @@ int avllm_clip_cls_rows(const void* ce, const void* pos, void* x, int32_t N, int
 int avllm_fuse_pool(const void* a, int32_t Ta, const void* v, int32_t Tv, const void* pe, int32_t P, void* out, int32_t B, int32_t L,
                     int32_t S_out, int32_t D, float fs, int32_t dtype, void* stream) { return av_fuse_pool(a, Ta, v, Tv, pe, P, out, B, L, S_out, D, fs, dtype, ST); }
 int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream) { return av_grad_sumsq(g, n, sumsq, ST); }
+int avllm_grad_sumsq_det(const float* g, int64_t n, float* partials, int32_t nparts, float* sumsq, void* stream) { return av_grad_sumsq_det(g, n, partials, nparts, sumsq, ST); }
 int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                      int32_t step, const float* sumsq, float max_norm, float prescale, const float* guard, float* skipped,
                      const avllm_step_state* state, void* stream) {

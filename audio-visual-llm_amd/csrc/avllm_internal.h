@@ -36,6 +36,7 @@ int av_clip_cls_rows(const void* class_emb, const void* pos, void* x, int N, int
 int av_fuse_pool(const void* a, int Ta, const void* v, int Tv, const void* prompt_emb, int P, void* out, int B, int L,
                  int S_out, int D, float fs, int dtype, hipStream_t st);
 int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st);
+int av_grad_sumsq_det(const float* g, long n, float* partials, int nparts, float* sumsq, hipStream_t st);
 int av_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const float* sumsq, float max_norm, float grad_prescale, const float* guard, float* skipped,
                   const avllm_step_state* state, hipStream_t st);

@@ -115,6 +115,30 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// The same sum in a FIXED order: block b writes its partial to partials[b] (block-internal order is fixed by block_sum), then one block adds
+// the partials in index order.  Data-parallel replicas compute the clip coefficient from identical all-reduced gradients: with float atomics
+// (sumsq_kernel) the last bits of the norm depend on arrival order, the replicas' parameters drift apart by ulps per step; with this form
+// they stay bit-identical.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
+    __shared__ float red[8];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(g + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ out) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
 // torch.optim.AdamW single-tensor rule (decoupled decay first), preceded by clip_grad_norm_'s scaling
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
@@ -224,6 +248,17 @@ int av_grad_sumsq(const float* g, long n, float* sumsq, hipStream_t st) {
     long blocks = (n / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, sumsq);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_grad_sumsq_det(const float* g, long n, float* partials, int nparts, float* sumsq, hipStream_t st) {
+    AV_CHECK_ARG(g && sumsq && partials && n > 0 && nparts >= 1, "grad_sumsq_det: bad args");
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > nparts ? nparts : blocks);
+    blocks = blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, g, n, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, partials, (int)blocks, sumsq);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -222,6 +222,9 @@ int avllm_fuse_pool(const void* a, int32_t Ta, const void* v, int32_t Tv, const 
  * Non-finite guard (trainer :444-452 skips backward + optimizer on a NaN/Inf loss): when *sumsq or *guard (e.g. the step's
  * loss_sum; may be NULL) is not finite the launch leaves p, m, v untouched and adds 1 to *skipped (device float, may be NULL). */
 int avllm_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+/* The same sum in a fixed order (no float atomics): *sumsq = sum g^2, overwritten.  partials = scratch of nparts floats (<= 1024 are used).
+ * Bit-reproducible, so data-parallel replicas that clip identical all-reduced gradients keep bit-identical parameters. */
+int avllm_grad_sumsq_det(const float* g, int64_t n, float* partials, int32_t nparts, float* sumsq, void* stream);
 int avllm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t step, const float* sumsq, float max_norm,
                      float grad_prescale, const float* guard, float* skipped, const avllm_step_state* state_dev, void* stream);

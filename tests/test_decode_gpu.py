@@ -239,8 +239,9 @@ def test_token_step_fused_matches_general_path_and_prefill(dev, hidden, heads, k
 def test_generate_bf16_fused_token_step_vs_oracle_greedy(dev, golden_dir, with_lora):
     """generate() in bf16 -- the arithmetic bench.py's decode{} times: prefill + the fused token step (asserted: avllm_llama_decode_is_fused) --
     against the ORACLE's greedy search on the reference-pinned tiny model (clip_whisper_model.py:1337-1340 -> HF greedy).  bf16 cannot promise
-    the fp32 token where the top-2 logits are closer than its own logit error, so each row is compared up to (not including) the first step
-    whose oracle margin is below 2 x the bf16 logit bar; from there on the two searches may legitimately walk different paths.  With and
+    the fp32 token where the top-2 logits are closer than its own logit error, so a row is followed for as long as the two searches agree:
+    at every step where the oracle's top-2 margin is at least 2 x the bf16 logit bar the token MUST be the oracle's; at a near-tie either
+    choice is accepted, and the row ends there if bf16 took the other one (the two searches then see different prefixes).  With and
     without adapters (decode.py runs without; the trainer's eval and `decode.py --load_lora` with)."""
     import numpy as np
     from bars import BF16_LOGIT_MAX_ABS
@@ -252,14 +253,14 @@ def test_generate_bf16_fused_token_step_vs_oracle_greedy(dev, golden_dir, with_l
     W = Wt.all_weights(oc, int(g["seed"]), lora_b_std=0.05)
     if not with_lora:
         W = {k: v for k, v in W.items() if k != "lora"}
-    audio, video, _, _ = Wt.synthetic_batch(oc, 2, int(g["frames"]), seed=int(g["batch_seed"]))
-    new = 16
+    audio, video, _, _ = Wt.synthetic_batch(oc, 4, int(g["frames"]), seed=int(g["batch_seed"]))
+    new = 24
     from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
     from avllm.model import ClipWhisperModel
     cfg = ModelCfg(WhisperCfg(**vars(oc.whisper)), ClipCfg(**vars(oc.clip)), LlamaCfg(**vars(oc.llama)), LoraCfg(oc.lora.r, oc.lora.alpha))
     m = ClipWhisperModel(device="cuda:0", use_lora=with_lora, lora_r=oc.lora.r, lora_alpha=oc.lora.alpha, lora_dropout=0.0, max_seq_len=256, config=cfg,
                          weights=W, precision="bf16").eval()
-    assert m.llm_engine.decode_is_fused(2), "the fused token step must take this model (bf16, B <= 16" + (", adapters" if with_lora else "") + ")"
+    assert m.llm_engine.decode_is_fused(4), "the fused token step must take this model (bf16, B <= 16" + (", adapters" if with_lora else "") + ")"
     ids = m.generate(audio=audio.to(dev), video=video.to(dev), max_new_tokens=new).cpu()
     oc.max_seq_len = 256
     ref, margins = O.generate(W, oc, audio, video, None, max_new_tokens=new, eos_token_id=m.eos_token_id, return_margins=True)
@@ -267,8 +268,10 @@ def test_generate_bf16_fused_token_step_vs_oracle_greedy(dev, golden_dir, with_l
     compared = 0
     for b in range(ref.shape[0]):
         for t in range(min(ref.shape[1], ids.shape[1])):
-            if float(margins[b, t]) < thr:
-                break
-            assert int(ids[b, t]) == int(ref[b, t]), (b, t, ids[b].tolist(), ref[b].tolist(), margins[b].tolist())
-            compared += 1
+            same = int(ids[b, t]) == int(ref[b, t])
+            if float(margins[b, t]) >= thr:
+                assert same, (b, t, ids[b].tolist(), ref[b].tolist(), margins[b].tolist())      # a clear decision of the oracle: bf16 must make it too
+                compared += 1
+            elif not same:
+                break                                            # a near-tie went the other way: from here on the two searches see different prefixes
     assert compared >= 8, (compared, margins.tolist())           # not vacuous: at least 8 tokens were held to the oracle's choice

@@ -356,7 +356,7 @@ def test_full_depth_bf16_train_step_vs_oracle(dev):
     # argmax identical wherever the oracle's top-2 margin exceeds the logit error this depth allows
     top2 = ologits.topk(2, dim=-1).values
     clear = (top2[..., 0] - top2[..., 1]) > 4.0 * Bar.bf16_depth_rel_l2(L) * float(ologits.std())
-    assert clear.float().mean() > 0.5
+    assert int(clear.sum()) >= 8, int(clear.sum())               # 32000 random logits: the top two are close at most positions; a handful are not
     assert torch.equal(logits.view_as(ologits).argmax(-1)[clear], ologits.argmax(-1)[clear])
     # (the negative control on the masks lives in test_g3_bench_shape_bf16_with_lora_dropout: a second oracle pass here would double the host time)
 
