@@ -92,6 +92,8 @@ _SIGS = {
     "avllm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "avllm_set_gemm_variant": ([i32], i32),
     "avllm_set_knob": ([C.c_char_p, i32], i32),
+    "avllm_im2col_k3": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "avllm_groupnorm_tokens": ([vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),
     "avllm_gemm_tn_drop": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, C.c_uint32, f32, i32, vp], i32),
     "avllm_logmel_table_bytes": ([], C.c_size_t),
@@ -190,7 +192,7 @@ class knob:
     """with knob("DECODE_FUSED", 0): ...   -- one of the library's A/B switches for the duration of the block (include/avllm.h
     avllm_set_knob; the table is otherwise filled once per process from AVLLM_<NAME>)."""
     _defaults = {"DECODE_FUSED": 1, "DEC_AL": 0, "LORA_UNBATCHED": 0, "F8_UNFUSED_QUANT": 0, "F8_FAST": 1, "ATTN_SHORT": 1,
-                 "NARROW_EPILOGUE": 0, "TN_CHUNK": 0, "GEMM_DBG": 0}
+                 "NARROW_EPILOGUE": 0, "TN_CHUNK": 0, "GEMM_DBG": 0, "GEMM_GW": 0}
 
     def __init__(self, name, value):
         self.name, self.value = name, int(value)

@@ -258,11 +258,18 @@ class ClipWhisperModel:
         use_a = self.modality in ("audio", "both") and audio is not None
         use_v = self.modality in ("video", "both") and video is not None
         if use_a and use_v:
-            Ta, Tv = self.cfg.whisper.n_ctx, video.shape[1]
-            Lc = min(self.max_seq_len, max(Ta, Tv))
-            a = self.encode_audio(audio, rows=min(Ta, Lc))
-            v = self.encode_video(video, rows=min(Tv, Lc))
-            return a, v, Lc
+            if self.connector_type not in ("conv", "attention", "adaptive"):
+                # per-token connectors (simple, deep = every unknown name): projecting only the rows that survive the truncation below is the
+                # same function at a third of the connector FLOPs
+                Ta, Tv = self.cfg.whisper.n_ctx, video.shape[1]
+                Lc = min(self.max_seq_len, max(Ta, Tv))
+                a = self.encode_audio(audio, rows=min(Ta, Lc))
+                v = self.encode_video(video, rows=min(Tv, Lc))
+                return a, v, Lc
+            # sequence-mixing connectors (conv / attention / adaptive) see the whole sequence, and `adaptive` changes its length (T > 512 -> T / 4):
+            # lengths are taken AFTER the connectors, as encode() does (:424-430)
+            a, v = self.encode_audio(audio), self.encode_video(video)
+            return a, v, min(self.max_seq_len, max(a.shape[1], v.shape[1]))
         if use_a:
             a = self.encode_audio(audio)
             return a, None, a.shape[1]

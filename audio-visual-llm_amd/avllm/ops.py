@@ -181,6 +181,41 @@ def act_residual(x, act, r=None):
     return y
 
 
+def conv1d_k3(x, w2d, bias, stride=1):
+    """nn.Conv1d(kernel_size=3, padding=1, stride) on token-major x [B,T,C]: avllm_im2col_k3 + avllm_gemm.  w2d = weight [out, C, 3] reshaped to
+    [out, kw*C + c] (permute(0, 2, 1)), zero-padded along K to a multiple of 64 by the caller when 3C is not one."""
+    B, T, Cc = x.shape
+    To = (T - 1) // stride + 1
+    K = w2d.shape[1]
+    x = x.contiguous()
+    cols = torch.empty(B * To, 3 * Cc, device=x.device, dtype=x.dtype) if K == 3 * Cc else torch.zeros(B * To, K, device=x.device, dtype=x.dtype)
+    if K == 3 * Cc:
+        L.check(L.load().avllm_im2col_k3(L.ptr(x), L.ptr(cols), B, T, Cc, stride, L.dt_of(x), L.stream_ptr()))
+    else:                                                       # padded K: im2col into a dense scratch, then one strided copy into the padded rows
+        dense = torch.empty(B * To, 3 * Cc, device=x.device, dtype=x.dtype)
+        L.check(L.load().avllm_im2col_k3(L.ptr(x), L.ptr(dense), B, T, Cc, stride, L.dt_of(x), L.stream_ptr()))
+        cols[:, : 3 * Cc] = dense
+    return gemm(cols, w2d, bias=bias).view(B, To, -1)
+
+
+def groupnorm_tokens(x, w, b, groups, eps=1e-5, act=L.ACT_NONE):
+    """nn.GroupNorm(groups, C) of the [B,C,T] view of x [B,T,C] (+ activation)."""
+    B, T, Cc = x.shape
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.load().avllm_groupnorm_tokens(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, T, Cc, groups, eps, act, L.dt_of(x), L.stream_ptr()))
+    return y
+
+
+def mha_self(x, in_w, in_b, out_w, out_b, heads):
+    """nn.MultiheadAttention(batch_first=True)(x, x, x) in eval mode: packed in-projection (avllm_gemm), softmax(QK^T / sqrt(hd)) V per head
+    (avllm_attention_fwd; head dims up to 512 go to the scalar kernel), out-projection.  x [B,T,E]."""
+    B, T, E = x.shape
+    qkv = gemm(x.reshape(B * T, E), in_w, bias=in_b)
+    o, _ = attention_fwd(qkv, B, T, heads, E // heads, causal=False, want_lse=False)
+    return gemm(o, out_w, bias=out_b).view(B, T, E)
+
+
 def fuse_pool(a, v, prompt_emb, L_, S_out, fusion_scale, D, B):
     """See avllm_fuse_pool in include/avllm.h.  a [B,Ta,D] | None, v [B,Tv,D] | None, prompt_emb [B,P,D] | None."""
     ref = a if a is not None else v

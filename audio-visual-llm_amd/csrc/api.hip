@@ -19,7 +19,7 @@ int av_set_error(int code, const char* fmt, ...) {
 #include <string.h>
 static const struct { const char* name; int dflt; } g_knob_def[AV_KNOB_COUNT] = {
     {"DECODE_FUSED", 1}, {"DEC_AL", 0}, {"LORA_UNBATCHED", 0}, {"F8_UNFUSED_QUANT", 0}, {"F8_FAST", 1}, {"ATTN_SHORT", 1},
-    {"NARROW_EPILOGUE", 0}, {"TN_CHUNK", 0}, {"GEMM_DBG", 0}};
+    {"NARROW_EPILOGUE", 0}, {"TN_CHUNK", 0}, {"GEMM_DBG", 0}, {"GEMM_GW", 0}};
 static int g_knob[AV_KNOB_COUNT];
 static std::once_flag g_knob_once;
 static void knob_init() {

@@ -22,12 +22,13 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ qs, const T* 
     return s;
 }
 
-// grid (ceil(Tq/4), H, B); wave w -> query t
-template <typename T>
+// grid (ceil(Tq/4), H, B); wave w -> query t.  NO = 64-wide chunks of the head dim a lane accumulates: 2 (head_dim <= 128: every model of the
+// path) or 8 (<= 512: the modality connectors' nn.MultiheadAttention, 8 heads over the LLM width -- modality_connector.py:186-191, 347-352)
+template <typename T, int NO>
 __global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                     T* __restrict__ o, float* __restrict__ lse, int Tq, int Tk, int H, int hd,
                                                     long ldq, long ldk, long ldv, long ldo, float scale, int causal, int G) {
-    __shared__ float qs[4][MAXHD];
+    __shared__ float qs[4][NO * 64];
     __shared__ float ps[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
@@ -36,7 +37,9 @@ __global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, con
     for (int c = lane; c < hd; c += 64) qs[w][c] = to_f(qr[c]);
     __builtin_amdgcn_wave_barrier();
     const int limit = causal ? t + (Tk - Tq) : Tk - 1;      // last visible key
-    float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+    float m = -INFINITY, l = 0.f, oacc[NO];
+#pragma unroll
+    for (int x = 0; x < NO; ++x) oacc[x] = 0.f;
     for (int kb = 0; kb <= limit && kb < Tk; kb += 64) {
         const int j = kb + lane;
         const bool valid = j < Tk && j <= limit;
@@ -50,19 +53,22 @@ __global__ __launch_bounds__(256) void attn_fwd_ref(const T* __restrict__ q, con
         __builtin_amdgcn_wave_barrier();
         ps[w][lane] = p;
         __builtin_amdgcn_wave_barrier();
-        o0 *= alpha; o1 *= alpha;
+#pragma unroll
+        for (int x = 0; x < NO; ++x) oacc[x] *= alpha;
         const int nj = min(64, min(Tk, limit + 1) - kb);
         for (int jj = 0; jj < nj; ++jj) {
             const T* vr = v + ((long)b * Tk + kb + jj) * ldv + (long)(h / G) * hd;
             const float pj = ps[w][jj];
-            if (lane < hd) o0 += pj * to_f(vr[lane]);
-            if (lane + 64 < hd) o1 += pj * to_f(vr[lane + 64]);
+#pragma unroll
+            for (int x = 0; x < NO; ++x)
+                if (lane + 64 * x < hd) oacc[x] += pj * to_f(vr[lane + 64 * x]);
         }
     }
     T* orow = o + ((long)b * Tq + t) * ldo + (long)h * hd;
     const float inv = 1.0f / l;
-    if (lane < hd) orow[lane] = from_f<T>(o0 * inv);
-    if (lane + 64 < hd) orow[lane + 64] = from_f<T>(o1 * inv);
+#pragma unroll
+    for (int x = 0; x < NO; ++x)
+        if (lane + 64 * x < hd) orow[lane + 64 * x] = from_f<T>(oacc[x] * inv);
     if (lse && lane == 0) lse[((long)b * H + h) * Tq + t] = m + logf(l);
 }
 
@@ -254,10 +260,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 
 int av_attention_fwd_ref(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
                          int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, hipStream_t st, int G) {
-    AV_CHECK_ARG(hd % 8 == 0 && hd <= MAXHD, "attention(ref): head_dim %d unsupported", hd);
+    AV_CHECK_ARG(hd % 8 == 0 && hd <= 4 * MAXHD, "attention(ref): head_dim %d unsupported (multiple of 8, <= 512)", hd);
     const dim3 grid(av_cdiv(Tq, 4), H, B);
-    if (dtype == AV_F32) hipLaunchKernelGGL((attn_fwd_ref<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, G);
-    else hipLaunchKernelGGL((attn_fwd_ref<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, G);
+#define AV_FWD_REF(TT, NOV) hipLaunchKernelGGL((attn_fwd_ref<TT, NOV>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)v, (TT*)o, lse, Tq, Tk, H, hd, ldq, ldk, ldv, ldo, scale, causal, G)
+    if (hd <= MAXHD) { if (dtype == AV_F32) AV_FWD_REF(float, 2); else AV_FWD_REF(bf16, 2); }
+    else { if (dtype == AV_F32) AV_FWD_REF(float, 8); else AV_FWD_REF(bf16, 8); }
+#undef AV_FWD_REF
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // layer or per launch.  Knobs that change what a production kernel computes or stores (GEMM_DBG) exist only in builds made with
 // -DAVLLM_EXPERIMENT_KNOBS.
 enum AvKnob { AV_KNOB_DECODE_FUSED, AV_KNOB_DEC_AL, AV_KNOB_LORA_UNBATCHED, AV_KNOB_F8_UNFUSED_QUANT, AV_KNOB_F8_FAST, AV_KNOB_ATTN_SHORT,
-              AV_KNOB_NARROW_EPILOGUE, AV_KNOB_TN_CHUNK, AV_KNOB_GEMM_DBG, AV_KNOB_COUNT };
+              AV_KNOB_NARROW_EPILOGUE, AV_KNOB_TN_CHUNK, AV_KNOB_GEMM_DBG, AV_KNOB_GEMM_GW, AV_KNOB_COUNT };
 int av_knob(int id);
 
 // ---- status / error string (thread local), SURVEY.md §8b "Errors" row

@@ -112,6 +112,7 @@ struct GemmArgs {
     long lda, ldb, lda2, ldb2;
     int K, K2;
     int wide_epi;        // outputs/bias/residual 16-byte aligned, N % 8 == 0: LDS-staged epilogue with 16-byte row-coalesced stores
+    int gw;              // persistent kernel, tall shapes: tile-column group width of the walk (gemm_shared.h tile_coords); 0 = plain row-major
     int dbg;             // experiment knobs of the persistent kernel (env AVLLM_GEMM_DBG): bit 0 = no epilogue stores, bit 1 = strict first-K-step wait, bit 2 = row-major tile order instead of 8 x 4 blocks, bit 3 = per-XCD contiguous id ranges instead of one block per XCD and round, bits 4.. = start-stagger phases (1 = off)
     EpiParams e;
 };
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     };
     auto set_ctx = [&](int vid) __attribute__((always_inline)) {
         int tm, tn;
-        tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
+        tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4), g.gw);
         lm0 = tm * HBM_; ln0 = tn * HBN_;
         const unsigned la2 = (unsigned)g.lda * 2, lb2 = (unsigned)g.ldb * 2, ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
 #pragma unroll
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         // 32p + 8fq .. +7 of row 16i + fr (acc[i][2p] = the first four, acc[i][2p+1] = the last four): bias / activation / residual on the
         // fp32 values, one rounding, one 16-byte store per pair; a store instruction covers 16 rows x 64 contiguous bytes.
         int tm, tn;
-        tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4));
+        tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4), g.gw);
         const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
         stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 3);      // dbg bit 1: experiment, strict wait      // wave-uniform: every lane stores all 32 chunks
         float b[4][8];
@@ -1280,7 +1281,7 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         GemmArgs g;
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
-        g.wide_epi = wide_ok; g.dbg = 0;
+        g.wide_epi = wide_ok; g.dbg = 0; g.gw = 0;
         hipLaunchKernelGGL(gemm_smallm_kernel, dim3(d->N / 16), dim3(SK_WAVES * 64), 0, st, g);
     } else if (d->dtype == AV_BF16 && d->N == 64 && d->K2 == 0 && !d->bias && !d->R && d->act == AV_ACT_NONE && d->g_in == 0 && d->drop_p <= 0.f &&
                d->K % (32 * SK_WAVES) == 0 && (d->M >= 256 || d->a_drop_p > 0.f)) {
@@ -1306,6 +1307,16 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
         g.wide_epi = wide_ok;
+        {   // tall shapes: walk the tiles in column groups whose weight panels fit an XCD's L2 beside the streaming activation panels
+            // (<= 1.6 MB of weights: 4 columns at K = 768, 1 at K >= 3072 -> no grouping), groups balanced over the columns
+            const int tn_ = av_cdiv(d->N, 256);
+            const long panel = 256L * (d->K + d->K2) * 2;
+            int gwmax = (int)((1600L << 10) / panel);
+            const int forced = av_knob(AV_KNOB_GEMM_GW);
+            g.gw = 0;
+            if (forced > 0) g.gw = forced;
+            else if (forced == 0 && gwmax >= 2 && tn_ > gwmax) g.gw = av_cdiv(tn_, av_cdiv(tn_, gwmax));
+        }
 #ifdef AVLLM_EXPERIMENT_KNOBS
         g.dbg = av_knob(AV_KNOB_GEMM_DBG);
 #else

@@ -34,7 +34,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn, int blocked = 0) {
+// gw > 0 (tall shapes, tiles_m > 32): COLUMN GROUPS of gw tile columns, ids run row-major inside a group (tn fastest) and group after group.
+// With one contiguous id range per XCD (xcd_remap) an XCD then works inside ONE group for most of the launch: its gw weight panels
+// (gw x 256 x K x 2 bytes: 1.2 - 1.6 MB at K = 768) stay L2-resident and each activation panel is fetched once per group and shared by the gw
+// CUs that hold its tiles at that moment.  Plain row-major order over all tiles_n columns (gw = 0) cycles the whole weight matrix (4.7 MB for the
+// CLIP fc1 > the 4 MiB L2) through every XCD: profiles/r03_pmc_gemm_shapes.txt measured 8.8x (fc1) / 5.3x (qkv) the algorithmic read bytes.
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn, int blocked = 0, int gw = 0) {
+    if (gw > 0 && tiles_m > 32 && tiles_n > gw) {
+        const int per_group = gw * tiles_m, ngf = tiles_n / gw, full = ngf * per_group;
+        if (id < full) {
+            const int grp = id / per_group, in = id - grp * per_group;
+            tm = in / gw; tn = grp * gw + (in - tm * gw);
+        } else {
+            const int r = id - full, rem = tiles_n - ngf * gw;
+            tm = r / rem; tn = ngf * gw + (r - tm * rem);
+        }
+        return;
+    }
     if (blocked && tiles_m <= 32 && tiles_m % 8 == 0) {
         // 8 x 4 blocks of tiles per 32 consecutive ids (an XCD's share of a round): half the activation panel and four weight panels per XCD
         // and round instead of the whole activation panel and two weight panels -- a third fewer bytes into each L2.  Measured on the

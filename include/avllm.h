@@ -65,7 +65,8 @@ int avllm_set_gemm_variant(int v);
  * (AVLLM_<NAME>) and changed afterwards only through this call.  Names: "DECODE_FUSED" (0 = general 10-launch decode layer),
  * "DEC_AL" (force an activation-load form of avllm_dec_proj: 2 | 4), "LORA_UNBATCHED" (1 = one launch per adapter), "F8_UNFUSED_QUANT"
  * (1 = separate quantiser passes), "F8_FAST" (0 = reference-grade fp8 GEMM), "ATTN_SHORT" (0 = general attention kernel for T <= 272),
- * "NARROW_EPILOGUE", "TN_CHUNK", "GEMM_DBG" (only read by builds made with -DAVLLM_EXPERIMENT_KNOBS).  Unknown name -> error. */
+ * "NARROW_EPILOGUE", "TN_CHUNK", "GEMM_GW" (tile-column group width of the persistent GEMM's walk on tall shapes: 0 automatic,
+ * -1 off, n forced), "GEMM_DBG" (only read by builds made with -DAVLLM_EXPERIMENT_KNOBS).  Unknown name -> error. */
 int avllm_set_knob(const char* name, int32_t value);
 
 /* out[I,J] (f32, row stride ldo) += alpha * sum_m P[m,i]*Q[m,j]; LoRA dA/dB (autograd of peft lora.Linear) */
@@ -151,6 +152,15 @@ typedef struct avllm_schedule {
     uint32_t rank;
 } avllm_schedule;
 int avllm_step_advance(avllm_step_state* state_dev, const avllm_schedule* sched, void* stream);
+
+/* Sequence operators of the non-default connectors (modality_connector.py:111-380), activations token-major [B, T, C]:
+ * im2col for nn.Conv1d(kernel_size 3, padding 1, stride 1 | 2): cols [B * Tout, 3 C], column kw * C + c = x[b, stride t' + kw - 1, c] (zero outside
+ * the sequence), Tout = (T - 1) / stride + 1; the convolution is then avllm_gemm with the weight reshaped to [out, kw * C + c]. */
+int avllm_im2col_k3(const void* x, void* cols, int32_t B, int32_t T, int32_t C, int32_t stride, int32_t dtype, void* stream);
+/* nn.GroupNorm(groups, C) of the [B, C, T] view of x [B, T, C]: mean / variance over (T, C / groups) per (item, group), affine w, b [C],
+ * then act (AVLLM_ACT_*).  (C / groups) % 8 == 0. */
+int avllm_groupnorm_tokens(const void* x, const void* w, const void* b, void* y, int32_t B, int32_t T, int32_t C, int32_t groups,
+                           float eps, int32_t act, int32_t dtype, void* stream);
 
 /* nn.LayerNorm (HF whisper :379-413, clip :362-384) */
 int avllm_layernorm(const void* x, const void* w, const void* b, void* y, int64_t rows, int32_t d, float eps,

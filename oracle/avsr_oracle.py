@@ -161,6 +161,66 @@ def connector(sd, x):
     return layer_norm(h @ sd["output_proj.weight"].T + sd["output_proj.bias"], sd["output_norm.weight"], sd["output_norm.bias"])
 
 
+def _conv1d_k3(x, w, b, stride=1):
+    """nn.Conv1d(kernel_size=3, padding=1, stride) on token-major x [B,T,C]: y[b,t',o] = b[o] + sum_{kw,c} w[o,c,kw] x[b, stride t' + kw - 1, c]."""
+    B, T, C = x.shape
+    xp = torch.cat([x.new_zeros(B, 1, C), x, x.new_zeros(B, 1, C)], 1)
+    To = (T + 2 - 3) // stride + 1
+    idx = torch.arange(To) * stride
+    cols = torch.cat([xp[:, idx + kw] for kw in range(3)], -1)                 # [B,To,3C], column kw*C + c
+    return cols @ w.permute(0, 2, 1).reshape(w.shape[0], -1).T + b
+
+
+def _group_norm_tokens(x, w, b, groups, eps=1e-5):
+    """nn.GroupNorm(groups, C) applied to [B,C,T], written for token-major x [B,T,C]: statistics over (T, C/groups) per (batch, group)."""
+    B, T, C = x.shape
+    g = x.view(B, T, groups, C // groups)
+    mu = g.mean((1, 3), keepdim=True)
+    var = ((g - mu) ** 2).mean((1, 3), keepdim=True)
+    return ((g - mu) * torch.rsqrt(var + eps)).view(B, T, C) * w + b
+
+
+def _mha(x, sd, prefix, heads):
+    """nn.MultiheadAttention(batch_first=True) self-attention in eval mode (its dropout 0.1 is off): packed in_proj, scaled dot product,
+    out_proj.  The reference runs it in train() mode during training, i.e. WITH dropout on the attention weights (torch's RNG stream: not
+    reproducible elsewhere); the restatement and the HIP path are the eval-mode function."""
+    B, T, E = x.shape
+    hd = E // heads
+    qkv = x @ sd[prefix + "in_proj_weight"].T + sd[prefix + "in_proj_bias"]
+    q, k, v = (t.view(B, T, heads, hd).transpose(1, 2) for t in qkv.split(E, -1))
+    a = softmax_attention(q, k, v, hd ** -0.5, causal=False)                  # [B,T,E]
+    return a @ sd[prefix + "out_proj.weight"].T + sd[prefix + "out_proj.bias"]
+
+
+def connector_conv(sd, x):
+    """ConvModalityConnector._forward_impl, modality_connector.py:158-172: Conv1d(k3) -> GroupNorm(8) -> GELU -> Conv1d(k3) -> GroupNorm(8)
+    over the sequence, then Linear -> LayerNorm."""
+    h = _group_norm_tokens(_conv1d_k3(x, sd["conv_layers.0.weight"], sd["conv_layers.0.bias"]), sd["conv_layers.1.weight"], sd["conv_layers.1.bias"], 8)
+    h = _group_norm_tokens(_conv1d_k3(gelu_erf(h), sd["conv_layers.3.weight"], sd["conv_layers.3.bias"]), sd["conv_layers.4.weight"], sd["conv_layers.4.bias"], 8)
+    return layer_norm(h @ sd["final_proj.weight"].T + sd["final_proj.bias"], sd["norm.weight"], sd["norm.bias"])
+
+
+def connector_attention(sd, x, heads=8):
+    """AttentionModalityConnector._forward_impl, modality_connector.py:218-238 (eval mode, see _mha)."""
+    h = layer_norm(x @ sd["input_proj.weight"].T + sd["input_proj.bias"], sd["norm1.weight"], sd["norm1.bias"])
+    h = layer_norm(_mha(h, sd, "attention.", heads) + h, sd["norm2.weight"], sd["norm2.bias"])
+    f = gelu_erf(h @ sd["ff.0.weight"].T + sd["ff.0.bias"]) @ sd["ff.2.weight"].T + sd["ff.2.bias"]
+    return layer_norm(f + h, sd["norm3.weight"], sd["norm3.bias"])
+
+
+def connector_adaptive(sd, x):
+    """AdaptiveModalityConnector._forward_impl, modality_connector.py:285-302, with PositionalEncoding :304-326 (the `pe` buffer of the state
+    dict) and AdaptiveSequencePooling.forward :362-380: sequences longer than 512 go through Conv1d(k3,s2) -> GELU -> Conv1d(k3,s2) (length / 4),
+    then self-attention (8 heads, eval mode) + residual + LayerNorm for every length."""
+    h = gelu_erf(layer_norm(x @ sd["input_proj.weight"].T + sd["input_proj.bias"], sd["norm1.weight"], sd["norm1.bias"]))
+    h = h + sd["pos_encoder.pe"][: h.shape[1]]
+    if h.shape[1] > 512:
+        h = _conv1d_k3(h, sd["adaptive_pool.long_adapter.0.weight"], sd["adaptive_pool.long_adapter.0.bias"], stride=2)
+        h = _conv1d_k3(gelu_erf(h), sd["adaptive_pool.long_adapter.2.weight"], sd["adaptive_pool.long_adapter.2.bias"], stride=2)
+    h = layer_norm(_mha(h, sd, "adaptive_pool.attn.", 8) + h, sd["adaptive_pool.norm.weight"], sd["adaptive_pool.norm.bias"])
+    return layer_norm(h @ sd["output_proj.weight"].T + sd["output_proj.bias"], sd["norm2.weight"], sd["norm2.bias"])
+
+
 def pad_or_truncate(x, target_len):
     """clip_whisper_model.py:320-374 (3-D branch)."""
     cur = x.shape[1]

@@ -43,6 +43,33 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "g9_deep_connector.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
+    # ---- round 3: conv / attention / adaptive (modality_connector.py:111-380), eval mode (their nn.MultiheadAttention carries dropout 0.1:
+    # a train()-mode forward of the reference draws from torch's RNG and is not reproducible outside it)
+    out = {}
+    cases = (("conv", "conv", 64, 128, 21, {}, O.connector_conv), ("attn", "attention", 64, 128, 19, {}, O.connector_attention),
+             ("adapt_short", "adaptive", 128, 128, 40, {"max_seq_len": 1536}, O.connector_adaptive),
+             ("adapt_long", "adaptive", 128, 128, 600, {"max_seq_len": 1536}, O.connector_adaptive))      # > 512 tokens: the strided-conv branch
+    for tag, name, din, dout, T, kw, fn in cases:
+        torch.manual_seed(100 + T)
+        conn = mc.create_modality_connector(name, din, dout, device="cpu", dtype=torch.float32, **kw).eval()
+        for p_ in conn.parameters():
+            if p_.dim() == 1:
+                p_.data.add_(0.1 * torch.randn_like(p_))
+        x = torch.randn(2, T, din)
+        with torch.no_grad():
+            y = conn(x)
+        sd = {k: v.detach().clone() for k, v in conn.state_dict().items()}
+        mine = fn(sd, x)
+        assert mine.shape == y.shape and (mine - y).abs().max() < 5e-5, (tag, mine.shape, y.shape, (mine - y).abs().max())
+        for k, v in sd.items():
+            if k == "pos_encoder.pe":
+                v = v[:T]                                            # only the rows a T-token input reads (the buffer has max_seq_len rows)
+            out[f"{tag}.sd.{k}"] = v.numpy()
+        out[f"{tag}.x"], out[f"{tag}.y"] = x.numpy(), y.numpy()
+        print(f"case {tag}: reference {type(conn).__name__} == oracle, max diff {(mine - y).abs().max():.1e}, out {tuple(y.shape)}")
+    path = os.path.join(ROOT, "tests", "golden", "g10_connectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

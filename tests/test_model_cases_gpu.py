@@ -211,5 +211,34 @@ def test_deep_connector_matches_reference_fixture(dev, golden_dir):
             c.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")})
             y = c(torch.from_numpy(g[tag + ".x"]).to(dev)).float().cpu()
             assert y.shape == (2, 9, 128) and (y - torch.from_numpy(g[tag + ".y"])).abs().max() < tol
-    with pytest.raises(NotImplementedError):
-        create_modality_connector("conv", 64, 128, device=dev)
+
+
+def test_conv_attention_adaptive_connectors_match_reference_fixture(dev, golden_dir):
+    """`connector_type` conv / attention / adaptive (modality_connector.py:111-380) against outputs of the REFERENCE's own classes in eval mode
+    on the same parameters (tests/golden/g10_connectors.npz, written by oracle/make_golden_connector.py): the reference's state dict loads as
+    it is (same module tree), the arithmetic is avllm_gemm / im2col / groupnorm / layernorm / attention.  adapt_long has 600 tokens, i.e. the
+    strided-convolution branch (T > 512 -> 150 rows)."""
+    import numpy as np
+    from avllm.connector import create_modality_connector
+    g = np.load(f"{golden_dir}/g10_connectors.npz")
+    for tag, name in (("conv", "conv"), ("attn", "attention"), ("adapt_short", "adaptive"), ("adapt_long", "adaptive")):
+        x, y = torch.from_numpy(g[tag + ".x"]), torch.from_numpy(g[tag + ".y"])
+        sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
+        for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 1e-1)):
+            kw = {"max_seq_len": sd["pos_encoder.pe"].shape[0]} if name == "adaptive" else {}
+            c = create_modality_connector(name, x.shape[-1], y.shape[-1], device=dev, dtype=dtype, **kw)
+            missing = c.load_state_dict(sd, strict=True)
+            out = c(x.to(dev)).float().cpu()
+            assert out.shape == y.shape, (tag, out.shape, y.shape)
+            err = (out - y).abs().max().item()
+            assert err < tol, (tag, str(dtype), err)
+    # the model accepts them by name (the reference's --connector_type choices, scripts/clip_whisper/train.py:76-78)
+    from avllm.arch import ClipCfg, LlamaCfg, LoraCfg, ModelCfg, WhisperCfg
+    from avllm.model import ClipWhisperModel
+    cfg = ModelCfg(WhisperCfg(128, 2, 2, 256), ClipCfg(128, 2, 2, 256, 48, 16), LlamaCfg(256, 2, 2, 512, 256), LoraCfg(16, 32.0))
+    oc = Wt.tiny()
+    audio, video, labels, prompt = batch(oc, 2, 3, seed=4)
+    for name in ("conv", "attention", "adaptive"):
+        m = ClipWhisperModel(device=dev, max_seq_len=512, config=cfg, precision="fp32", seed=3, synthetic_weights=True, connector_type=name).train()
+        out = m(audio=audio.to(dev), video=video.to(dev), prompt=prompt.to(dev), labels=labels.to(dev))
+        assert torch.isfinite(out["loss"]).item() and out["logits"].shape[:2] == (2, 256), name

@@ -168,3 +168,12 @@ def test_deep_connector_golden(golden_dir):
         sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
         y = O.connector(sd, torch.from_numpy(g[tag + ".x"]))
         assert (y - torch.from_numpy(g[tag + ".y"])).abs().max() < 2e-6
+
+
+def test_connector_restatements_match_reference_fixture(golden_dir):
+    """oracle conv / attention / adaptive connectors == the reference's own modules (fixture g10, eval mode)."""
+    g = np.load(f"{golden_dir}/g10_connectors.npz")
+    for tag, fn in (("conv", O.connector_conv), ("attn", O.connector_attention), ("adapt_short", O.connector_adaptive), ("adapt_long", O.connector_adaptive)):
+        sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
+        y = fn(sd, torch.from_numpy(g[tag + ".x"]))
+        assert y.shape == g[tag + ".y"].shape and (y - torch.from_numpy(g[tag + ".y"])).abs().max() < 5e-5, tag
