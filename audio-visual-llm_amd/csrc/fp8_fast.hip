@@ -260,10 +260,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
             for (int i = 0; i < 8; ++i) {
                 const bool mrow = m0 + i * 16 < g.M;
 #pragma clang loop unroll(full)
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p) {
+                    // the accumulators are "redefined" here for the compiler: otherwise every epilogue variant's 256 accumulator reads are hoisted above
+                    // the variant branch as common subexpressions (256 live registers: 57 spilled VGPRs, 460 scratch accesses around the epilogue)
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
                     if (mrow && n + 32 * p < g.N && !(g.dbg & 1))
                         epilogue_fast8<ACT>(acc[i][2 * p], acc[i][2 * p + 1], b[p], g.bias != nullptr, rp0 ? rp0 + (i * 16) * ldr + 32 * p : nullptr,
                                             cp0 + (i * 16) * ldc + 32 * p);
+                }
             }
         };
         // Quantised output: act(acc + bias) -> e4m3 + one E8M0 per 32 columns, from the fp32 values (the separate quantiser pass over a bf16
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
                 const bool mrow = m0 + i * 16 < g.M;
 #pragma clang loop unroll(full)
                 for (int p = 0; p < 4; ++p) {
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
                     const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     if (g.bias != nullptr) {

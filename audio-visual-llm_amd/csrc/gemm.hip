@@ -724,7 +724,21 @@ __device__ __forceinline__ void wpgemm_kstep(std::integer_sequence<int, Ns...>, 
     (wpgemm_step<Ns, MODE>(acc, FA, FB, la, lb, vA, vB, pA, pB, m0A, m0B), ...);
 }
 
+#ifndef WP_RES_DEPTH
+#define WP_RES_DEPTH 7
+#endif
 constexpr int WP_LDS = 2 * HSTAGE;                                  // two stage buffers; the epilogue does not touch LDS
+
+// Diagnostic build only (-DAVLLM_GEMM_STAMPS, tools/gemm_stamps.sh): s_memtime stamps at the K-step boundaries of the persistent kernel, summed
+// per wave into a buffer nothing else reads: [workgroup][wave][0: first K-step of a tile, 1: second, 2: the others, 3: epilogue (VALU + store
+// issue), 4: fragment re-read, 5: tiles, 6: s_memtime span of the wave, 7: s_memrealtime span].  The shipped kernel executes no stamp.
+#ifdef AVLLM_GEMM_STAMPS
+__device__ unsigned long long g_wp_stamps[256 * 4 * 8];
+#define WP_STAMP(slot) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                            __builtin_amdgcn_sched_barrier(0); st_acc[slot] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define WP_STAMP(slot) do { } while (0)
+#endif
 
 template <bool HAS2>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
@@ -847,11 +861,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         advance();
     };
     bool stores_in_flight = false;                                   // the previous tile's epilogue issued all of its 32 stores
+#ifdef AVLLM_GEMM_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev, st_t0, st_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0) :: "memory");
+    st_prev = st_t0;
+#endif
     for (int vid = blockIdx.x; vid < ntiles; vid += G) {
         if (stores_in_flight) kstep(std::integral_constant<int, 2>{});
         else kstep(std::integral_constant<int, 1>{});
+        WP_STAMP(0);
+#ifdef AVLLM_GEMM_STAMPS
+        if (nt > 1) { kstep(std::integral_constant<int, 0>{}); WP_STAMP(1); }
+#pragma unroll 1
+        for (int t = 2; t < nt; ++t) kstep(std::integral_constant<int, 0>{});
+        WP_STAMP(2);
+#else
 #pragma unroll 1
         for (int t = 1; t < nt; ++t) kstep(std::integral_constant<int, 0>{});
+#endif
         // result latency of the last MFMAs (invisible to the compiler's hazard recogniser): nops, and every accumulator named as an in/out
         // operand so that compiler-generated readers stay behind them
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -864,7 +891,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         int tm, tn;
         tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4), g.gw);
         const int m0 = tm * HBM_ + wr * 128 + fr, n = tn * HBN_ + wc * 128 + fq * 8;
-        stores_in_flight = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 3);      // dbg bit 1: experiment, strict wait      // wave-uniform: every lane stores all 32 chunks
+        const bool full = (tm + 1) * HBM_ <= g.e.M && (tn + 1) * HBN_ <= g.e.N && !(g.dbg & 3);      // wave-uniform: every lane stores all 32 chunks
+        stores_in_flight = full;                                     // dbg bit 1: experiment, strict wait
+        // (the bias cannot ride in the accumulators' initial value: an MFMA's C and D operands share one register-file bit, and D is an AGPR)
         float b[4][8];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -876,28 +905,59 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         bf16* const cp0 = (bf16*)g.e.C + (long)m0 * g.e.ldc + n;
         const bf16* const rp0 = g.e.R ? (const bf16*)g.e.R + (long)m0 * g.e.ldr + n : nullptr;
         const long ldc = g.e.ldc, ldr = g.e.R ? g.e.ldr : 0;
+        // edge tiles (and activation + residual, which no model call makes): per-chunk bounds tests
         auto run = [&](auto actc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(actc)::value;
 #pragma clang loop unroll(full)
             for (int i = 0; i < 8; ++i) {
                 const bool mrow = m0 + i * 16 < g.e.M;
 #pragma clang loop unroll(full)
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p) {
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
                     if (mrow && n + 32 * p < g.e.N && !(g.dbg & 1))
                         epilogue_fast8<ACT>(acc[i][2 * p], acc[i][2 * p + 1], b[p], g.e.bias != nullptr, rp0 ? rp0 + (i * 16) * ldr + 32 * p : nullptr,
                                             cp0 + (i * 16) * ldc + 32 * p);
+                }
             }
         };
-        // Residual without activation on a full tile (out-projection, fc2, o, down, gradient sums): the residual rows are fetched ONE ROW BLOCK
-        // AHEAD of the stores.  In `run` a residual load sits behind the previous chunk's store, which may alias it (in-place residual), so it
-        // cannot be hoisted and every chunk pays load -> vmcnt(0) -> store: clip out-projection 442 us without residual, 650 us with.
-        // The loads are inline asm with explicit vmcnt waits (VMEM operations of a wave complete in issue order): compiler-visible loads
-        // consumed later leave the wait-count pass with "pending" state at the joins, which reaches the K loop as a vmcnt(0) per K-step
-        // (measured: every GEMM 10 % slower).  Extra compiler-made VMEM operations (spill reloads) between them only make a wait longer.
-        auto run_res = [&]() __attribute__((always_inline)) {
-            // residual row blocks in flight ahead of the one being stored.  2 or 3 cost 28 spilled registers whose scratch reloads put
-            // compiler-made waits (vmcnt(14) .. vmcnt(6)) into the K loop: llama o-projection 108 -> 138 us (tests/test_codegen_cpu.py guards this)
-            constexpr int RD = 1;
+        // full tile, no residual: 8 accumulator reads, 8 bias adds (only in the instantiation with a bias), the activation, 4 packed converts and
+        // one 16-byte store per chunk -- no bounds test, no select, no branch (the general form above spends ~40 instructions per chunk:
+        // tools/gemm_stamps.py measured the epilogue at a quarter of a K = 768 tile)
+        auto run_full = [&](auto actc, auto hasbc) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(actc)::value;
+            constexpr bool HASB = decltype(hasbc)::value;
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 8; ++i) {
+                bf16* const cpi = cp0 + (long)(i * 16) * ldc;
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 4; ++p) {
+                    // the accumulators are "redefined" here for the compiler: without it every epilogue variant's 256 accumulator reads are hoisted
+                    // above the variant branch as common subexpressions -- 256 live registers, ~130 spills around the epilogue
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
+                    const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if constexpr (HASB) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] += b[p][c];
+                    }
+                    if constexpr (ACT != AV_ACT_NONE) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = act_apply_fast(v[c], ACT);
+                    }
+                    store_f<8>(cpi + 32 * p, v);
+                }
+            }
+        };
+        // full tile + residual (out-projection, fc2, o, down, gradient sums): ALL 32 residual chunks of the lane are requested in one burst into
+        // the 128 registers the operand fragments occupy during the K loop (dead here: the next tile's are re-read after the epilogue), then
+        // consumed in issue order.  The tile pays one memory latency instead of one per row block (tools/gemm_stamps.py: 12 us of a 29 us
+        // out-projection tile with the one-row-block-ahead form).  A load may alias a later store (in-place residual): every load is issued
+        // before the first store, and a lane only ever reads the bytes it writes itself.  Behind chunk c's load at its wait: 31 - c younger
+        // loads and the c stores issued so far = 31 operations, whatever c: one constant vmcnt.  asm loads + explicit waits because
+        // compiler-visible loads consumed later leave the wait-count pass with pending state that reaches the K loop as vmcnt(0) per K-step.
+        auto run_res_full = [&](auto hasbc) __attribute__((always_inline)) {
+            constexpr bool HASB = decltype(hasbc)::value;
+            constexpr int RD = WP_RES_DEPTH;                         // residual row blocks requested ahead of the one being stored (7 = the whole tile at once)
             u32x4 rr[RD + 1][4];
             auto fetch = [&](int i) __attribute__((always_inline)) {
                 const bf16* rp = rp0 + (long)(i * 16) * ldr;
@@ -906,44 +966,61 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
                              : "=&v"(rr[i % (RD + 1)][0]), "=&v"(rr[i % (RD + 1)][1]), "=&v"(rr[i % (RD + 1)][2]), "=&v"(rr[i % (RD + 1)][3]) : "v"(rp) : "memory");
             };
 #pragma clang loop unroll(full)
-            for (int i = 0; i < RD; ++i) fetch(i);
+            for (int i = 0; i < RD && i < 8; ++i) fetch(i);
 #pragma clang loop unroll(full)
             for (int i = 0; i < 8; ++i) {
                 if (i + RD < 8) fetch(i + RD);
-                // younger operations behind a load of row i at its wait: 3 of its own row / earlier stores of the row, 4 per later row in
-                // flight, 4 per row stored since the load was issued
-                const int nw = 3 + 4 * (RD < 7 - i ? RD : 7 - i) + 4 * (RD < i ? RD : i);
+                bf16* const cpi = cp0 + (long)(i * 16) * ldc;
+                // younger operations behind row block i's loads at their wait: 3 of its own asm statement, 4 per later row block in flight,
+                // 4 stores per row block stored since the loads were issued (all of them = 31 with the whole tile in flight)
+                constexpr int dummy = 0; (void)dummy;
+                const int ahead = (i + RD < 8 ? i + RD : 7) - i, behind = RD < i ? RD : i;
 #pragma clang loop unroll(full)
                 for (int p = 0; p < 4; ++p) {
                     u32x4& x = rr[i % (RD + 1)][p];
+                    const int nw = 3 + 4 * ahead + 4 * behind;
                     if (nw == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(x) :: "memory");
                     else if (nw == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(x) :: "memory");
                     else if (nw == 15) asm volatile("s_waitcnt vmcnt(15)" : "+v"(x) :: "memory");
                     else if (nw == 19) asm volatile("s_waitcnt vmcnt(19)" : "+v"(x) :: "memory");
                     else if (nw == 23) asm volatile("s_waitcnt vmcnt(23)" : "+v"(x) :: "memory");
                     else if (nw == 27) asm volatile("s_waitcnt vmcnt(27)" : "+v"(x) :: "memory");
+                    else if (nw == 31) asm volatile("s_waitcnt vmcnt(31)" : "+v"(x) :: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(x) :: "memory");
                     const bf16x8 r = __builtin_bit_cast(bf16x8, x);
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
                     const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (g.e.bias != nullptr) {
+                    if constexpr (HASB) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) v[c] += b[p][c];
                     }
 #pragma unroll
                     for (int c = 0; c < 8; ++c) v[c] += (float)r[c];
-                    store_f<8>(cp0 + (i * 16) * ldc + 32 * p, v);
+                    store_f<8>(cpi + 32 * p, v);
                 }
             }
         };
-        if (stores_in_flight && g.e.R && g.e.act == AV_ACT_NONE) run_res();       // stores_in_flight == full tile (and no debug knobs)
+        // the combinations the model calls make get the lean forms; anything else (and every edge tile) the general one
+        const std::true_type yes{};
+        const std::false_type no{};
+        const bool hb = g.e.bias != nullptr;
+        if (full && !g.e.R && g.e.act == AV_ACT_NONE && !hb) run_full(std::integral_constant<int, AV_ACT_NONE>{}, no);           // Llama projections, gradient GEMMs
+        else if (full && !g.e.R && g.e.act == AV_ACT_NONE && hb) run_full(std::integral_constant<int, AV_ACT_NONE>{}, yes);     // encoder q|k|v
+        else if (full && !g.e.R && g.e.act == AV_ACT_GELU && hb) run_full(std::integral_constant<int, AV_ACT_GELU>{}, yes);     // Whisper fc1
+        else if (full && !g.e.R && g.e.act == AV_ACT_QUICK_GELU && hb) run_full(std::integral_constant<int, AV_ACT_QUICK_GELU>{}, yes);      // CLIP fc1
+        else if (full && g.e.R && g.e.act == AV_ACT_NONE && hb) run_res_full(yes);                                                // encoder out-projection / fc2
+        else if (full && g.e.R && g.e.act == AV_ACT_NONE) run_res_full(no);                                                       // Llama o / down, gradient sums
         else if (g.e.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
         else if (g.e.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
         else if (g.e.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
         else run(std::integral_constant<int, AV_ACT_SILU>{});
+        WP_STAMP(3);
         // The next tile's k-half-0 fragments are read again here (its first K-step is complete in the current buffer: the last K-step's
         // barrier covered it) instead of being carried through the epilogue: 64 registers the epilogue code can use
-        if (vid + G < ntiles) {
+        // (unconditional: after the workgroup's last tile the reads fetch stale LDS bytes nobody uses -- a conditional re-read keeps the 64
+        // fragment registers live through the epilogue on the not-taken path, which the residual burst above needs)
+        {
             int a0 = la[1] - pc1 + pc0;
             const int b0 = lb[1] - pcB1 + pcB0;
             AV_WP_RDB(0); AV_WP_RDB(1); AV_WP_RDB(2); AV_WP_RDB(3); AV_WP_RDB(4); AV_WP_RDB(5); AV_WP_RDB(6); AV_WP_RDB(7);
@@ -951,8 +1028,23 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
             for (int i = 0; i < 8; ++i) { AV_W_RD(FA[0][i], a0, 0); a0 += 2048; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        WP_STAMP(4);
+#ifdef AVLLM_GEMM_STAMPS
+        st_acc[5] += 1;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // in-flight DMA writes must not outlive the workgroup's LDS allocation
+#ifdef AVLLM_GEMM_STAMPS
+    {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+        if (lane == 0 && blockIdx.x < 256) {
+            unsigned long long* o = g_wp_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+            o[6] = t1 - st_t0; o[7] = r1 - st_r0;
+        }
+    }
+#endif
 #undef AV_WP_RDB
 #undef AV_W_RD
 #undef AV_W_LD
@@ -1252,6 +1344,13 @@ static GemmDevState* gemm_dev_state() {
     if (!s->ncu && hipDeviceGetAttribute(&s->ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) s->ncu = 256;
     return s;
 }
+#ifdef AVLLM_GEMM_STAMPS
+extern "C" int avllm_debug_read_gemm_stamps(unsigned long long* host, int32_t n) {
+    AV_HIP(hipDeviceSynchronize());
+    AV_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wp_stamps), sizeof(unsigned long long) * (size_t)(n < 256 * 4 * 8 ? n : 256 * 4 * 8)));
+    return AV_OK;
+}
+#endif
 static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave, 8 256x256 4-wave persistent (lean epilogue only)
 extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
@@ -1307,15 +1406,12 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.A2 = (const bf16*)d->A2; g.B2 = (const bf16*)d->B2;
         g.lda = d->lda; g.ldb = d->ldb; g.lda2 = d->lda2; g.ldb2 = d->ldb2; g.K = d->K; g.K2 = d->K2; g.e = e;
         g.wide_epi = wide_ok;
-        {   // tall shapes: walk the tiles in column groups whose weight panels fit an XCD's L2 beside the streaming activation panels
-            // (<= 1.6 MB of weights: 4 columns at K = 768, 1 at K >= 3072 -> no grouping), groups balanced over the columns
-            const int tn_ = av_cdiv(d->N, 256);
-            const long panel = 256L * (d->K + d->K2) * 2;
-            int gwmax = (int)((1600L << 10) / panel);
+        {   // Tall shapes can walk the tiles in column groups whose weight panels fit an XCD's L2 beside the streaming activation panels.
+            // Measured (profiles/r03_pmc_gemm_shapes.txt, gpurun_out/r3_gw_sweep.log): the fabric reads of the CLIP fc1 fall from 8.8x to 4.6x
+            // the algorithmic bytes (qkv 5.3x -> 4.1x) and the launch gets no faster (fc1 1688 -> 1670 us at width 6, 1751 at 4; qkv 1263 ->
+            // 1293 .. 1324): these launches are not bound by their read traffic.  So the walk stays row-major; knob GEMM_GW = n forces a width.
             const int forced = av_knob(AV_KNOB_GEMM_GW);
-            g.gw = 0;
-            if (forced > 0) g.gw = forced;
-            else if (forced == 0 && gwmax >= 2 && tn_ > gwmax) g.gw = av_cdiv(tn_, av_cdiv(tn_, gwmax));
+            g.gw = forced > 0 ? forced : 0;
         }
 #ifdef AVLLM_EXPERIMENT_KNOBS
         g.dbg = av_knob(AV_KNOB_GEMM_DBG);

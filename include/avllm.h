@@ -65,8 +65,8 @@ int avllm_set_gemm_variant(int v);
  * (AVLLM_<NAME>) and changed afterwards only through this call.  Names: "DECODE_FUSED" (0 = general 10-launch decode layer),
  * "DEC_AL" (force an activation-load form of avllm_dec_proj: 2 | 4), "LORA_UNBATCHED" (1 = one launch per adapter), "F8_UNFUSED_QUANT"
  * (1 = separate quantiser passes), "F8_FAST" (0 = reference-grade fp8 GEMM), "ATTN_SHORT" (0 = general attention kernel for T <= 272),
- * "NARROW_EPILOGUE", "TN_CHUNK", "GEMM_GW" (tile-column group width of the persistent GEMM's walk on tall shapes: 0 automatic,
- * -1 off, n forced), "GEMM_DBG" (only read by builds made with -DAVLLM_EXPERIMENT_KNOBS).  Unknown name -> error. */
+ * "NARROW_EPILOGUE", "TN_CHUNK", "GEMM_GW" (tile-column group width of the persistent GEMM's walk on tall shapes: 0 = row-major walk,
+ * n = groups of n columns), "GEMM_DBG" (only read by builds made with -DAVLLM_EXPERIMENT_KNOBS).  Unknown name -> error. */
 int avllm_set_knob(const char* name, int32_t value);
 
 /* out[I,J] (f32, row stride ldo) += alpha * sum_m P[m,i]*Q[m,j]; LoRA dA/dB (autograd of peft lora.Linear) */
