@@ -326,12 +326,87 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
                 if (tn * TN + wc * 128 + 32 * fq < g.N && rb < RBo) g.SCq[(((long)t * RBo + rb) * 4 + fq) * 16 + fr] = wv;
             }
         };
+        // full tile, bf16 output: the lean forms of gemm_bf16_wp_kernel (no bounds test, no select, no branch per chunk; with a residual, all 32
+        // residual chunks of the lane requested in one burst into registers that are dead here and consumed behind ONE constant wait count:
+        // 31 - c younger loads + c stores behind chunk c's load)
+        const bool full = relaxed;
+        auto run_full = [&](auto actc, auto hasbc) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(actc)::value;
+            constexpr bool HASB = decltype(hasbc)::value;
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 8; ++i) {
+                bf16* const cpi = cp0 + (long)(i * 16) * ldc;
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 4; ++p) {
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
+                    const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if constexpr (HASB) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] += b[p][c];
+                    }
+                    if constexpr (ACT != AV_ACT_NONE) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = act_apply_fast(v[c], ACT);
+                    }
+                    store_f<8>(cpi + 32 * p, v);
+                }
+            }
+        };
+        auto run_res_full = [&](auto hasbc) __attribute__((always_inline)) {
+            constexpr bool HASB = decltype(hasbc)::value;
+            // one row block of residual chunks ahead of the stores (this kernel carries the next tile's 128 fragment registers through the
+            // epilogue, so the whole-tile burst of the bf16 kernel does not fit): asm loads + hand-counted waits, see gemm.hip
+            constexpr int RD = 1;
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+            u32x4_ rr[RD + 1][4];
+            auto fetch = [&](int i) __attribute__((always_inline)) {
+                const bf16* rp = rp0 + (long)(i * 16) * ldr;
+                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                             : "=&v"(rr[i % (RD + 1)][0]), "=&v"(rr[i % (RD + 1)][1]), "=&v"(rr[i % (RD + 1)][2]), "=&v"(rr[i % (RD + 1)][3]) : "v"(rp) : "memory");
+            };
+            fetch(0);
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 8; ++i) {
+                if (i + RD < 8) fetch(i + RD);
+                bf16* const cpi = cp0 + (long)(i * 16) * ldc;
+                const int nw = 3 + 4 * (RD < 7 - i ? RD : 7 - i) + 4 * (RD < i ? RD : i);
+#pragma clang loop unroll(full)
+                for (int p = 0; p < 4; ++p) {
+                    u32x4_& x = rr[i % (RD + 1)][p];
+                    if (nw == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(x) :: "memory");
+                    else if (nw == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(x) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(x) :: "memory");
+                    const bf16x8 r = __builtin_bit_cast(bf16x8, x);
+                    asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
+                    const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if constexpr (HASB) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] += b[p][c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] += (float)r[c];
+                    store_f<8>(cpi + 32 * p, v);
+                }
+            }
+        };
+        const std::true_type yes{};
+        const std::false_type no{};
+        const bool hb = g.bias != nullptr;
         if (g.Cq) {
             if (g.act == AV_ACT_NONE) run_q(std::integral_constant<int, AV_ACT_NONE>{});
             else if (g.act == AV_ACT_GELU) run_q(std::integral_constant<int, AV_ACT_GELU>{});
             else if (g.act == AV_ACT_QUICK_GELU) run_q(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
             else run_q(std::integral_constant<int, AV_ACT_SILU>{});
-        } else if (g.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
+        } else if (full && !g.R && g.act == AV_ACT_NONE && !hb) run_full(std::integral_constant<int, AV_ACT_NONE>{}, no);
+        else if (full && !g.R && g.act == AV_ACT_NONE && hb) run_full(std::integral_constant<int, AV_ACT_NONE>{}, yes);
+        else if (full && !g.R && g.act == AV_ACT_GELU && hb) run_full(std::integral_constant<int, AV_ACT_GELU>{}, yes);
+        else if (full && !g.R && g.act == AV_ACT_QUICK_GELU && hb) run_full(std::integral_constant<int, AV_ACT_QUICK_GELU>{}, yes);
+        else if (full && g.R && g.act == AV_ACT_NONE && hb) run_res_full(yes);
+        else if (full && g.R && g.act == AV_ACT_NONE) run_res_full(no);
+        else if (g.act == AV_ACT_NONE) run(std::integral_constant<int, AV_ACT_NONE>{});
         else if (g.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
         else if (g.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
         else run(std::integral_constant<int, AV_ACT_SILU>{});
