@@ -219,12 +219,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
     const int krow = kpos < T ? kpos : T - 1;
     const float sl = scale * 1.4426950408889634f;
 
-    bf16x8 kf[HD / 16], vf[HD / 16];                     // B operands: lane holds K[key r][16ks + 8half ..], V likewise
+    // B operands: lane holds K[key r][16ks + 8half ..] in registers for the whole kernel.  The V fragments of the same shape are parked in a
+    // wave-private LDS slice and read back where dP needs them (HD = 128: with both sets in registers the kernel needs ~282 VGPRs against the 256
+    // of two waves per SIMD -- 26 spilled registers whose scratch traffic sat in the loop; rocprof: 62 % of the wave cycles waiting)
+    constexpr bool V_LDS = HD > 64;
+    __shared__ __attribute__((aligned(16))) char v_keep[V_LDS ? NW * 32 * RS : 16];
+    char* const vk = v_keep + (V_LDS ? (w * 32 + r) * RS + half * 16 : 0);
+    bf16x8 kf[HD / 16], vf[V_LDS ? 1 : HD / 16];
     {
         const bf16* kp = k + ((long)b * T + krow) * ldk + (long)hh * HD + 8 * half;
         const bf16* vp = v + ((long)b * T + krow) * ldv + (long)hh * HD + 8 * half;
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) { kf[ks] = *(const bf16x8*)(kp + 16 * ks); vf[ks] = *(const bf16x8*)(vp + 16 * ks); }
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            kf[ks] = *(const bf16x8*)(kp + 16 * ks);
+            if constexpr (V_LDS) *(bf16x8*)(vk + 32 * ks) = *(const bf16x8*)(vp + 16 * ks);      // same lane reads it back: no barrier
+            else vf[ks] = *(const bf16x8*)(vp + 16 * ks);
+        }
     }
     f32x16 dka[HD / 32], dva[HD / 32];
 #pragma unroll
@@ -269,9 +279,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
             const bf16x8 qa = *(const bf16x8*)(q_row + r * RS + (2 * ks + half) * 16);
             const bf16x8 da = *(const bf16x8*)(do_row + r * RS + (2 * ks + half) * 16);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);       // S[query][key]
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);     // dP[query][key]
+            bf16x8 vb;
+            if constexpr (V_LDS) vb = *(const bf16x8*)(vk + 32 * ks); else vb = vf[ks];
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vb, dp, 0, 0, 0);         // dP[query][key]
         }
-        f32x16 p;
+        // P and dS leave the fp32 accumulators as packed bf16 straight away (they are only ever MFMA operands): the two extra 16-register
+        // fp32 copies this loop used to hold pushed the kernel 26 registers over its 256 (two waves per SIMD), and the spill traffic sat in
+        // the loop (rocprof: 62 % of the wave cycles waiting)
+        bf16x8 pbs[2], dsbs[2];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g4 + 4 * half);
@@ -282,15 +297,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_mfma(const bf16* __re
                 const int qi = qb + 8 * g4 + 4 * half + j;
                 const bool ok = qi < T && kpos < T && (!CAUSAL || kpos <= qi);
                 const float pv = ok ? __builtin_amdgcn_exp2f(s[i] * sl - l4[j]) : 0.f;
-                p[i] = pv;
-                s[i] = pv * (dp[i] - d4[j]) * scale;        // dS[query][key]
+                pbs[g4 >> 1][4 * (g4 & 1) + j] = (bf16)pv;
+                dsbs[g4 >> 1][4 * (g4 & 1) + j] = (bf16)(pv * (dp[i] - d4[j]) * scale);        // dS[query][key]
             }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            bf16x8 pb, dsb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { pb[j] = (bf16)p[8 * st + j]; dsb[j] = (bf16)s[8 * st + j]; }
+            const bf16x8 pb = pbs[st], dsb = dsbs[st];
 #pragma unroll
             for (int d = 0; d < HD / 32; ++d) {
                 const bf16x8 dot = tr_frag(do_tr, TS, 16 * st, 32 * d, lane);

@@ -76,6 +76,10 @@ __device__ __forceinline__ void f8_mfma(f32x4& acc, const v8i fb, const v8i fa, 
 
 struct F8Frag { v4i lo, hi; };
 
+template <int I, int N, class F> __device__ __forceinline__ void f8_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); f8_static_for<I + 1, N>(f); }
+}
+
 // Slot N of a K-step.  ONE instantiation serves every K-step of every tile (the tile boundary is a cold block inside the K-step loop: a
 // separate copy of this 64-MFMA body for "first K-step of a tile" made the register allocator permute the 128 fragment registers through
 // scratch at every tile boundary).  `relaxed`: this is the first K-step after a full epilogue, whose stores may stay in flight (gemm.hip
@@ -277,13 +281,17 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
         // CONSUMER (128 columns): this lane's row blocks i = 4 a + i' fill whole words; lane fq writes the words of block p == fq.
         auto run_q = [&](auto actc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(actc)::value;
-            uint32_t sw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            // the eight scale words of the lane as named scalars, updated through compile-time indices (f8_static_for): as an array indexed by
+            // the unrolled loop variables they stayed in scratch memory -- a scratch load + vmcnt(0) + scratch store behind every chunk's
+            // global store, i.e. one store acknowledgement of latency per chunk
+            uint32_t sw00 = 0u, sw01 = 0u, sw02 = 0u, sw03 = 0u, sw10 = 0u, sw11 = 0u, sw12 = 0u, sw13 = 0u;
             uint8_t* const qp0 = g.Cq + (long)m0 * g.ldcq + n;
-#pragma clang loop unroll(full)
-            for (int i = 0; i < 8; ++i) {
+            const long ldcq = g.ldcq;
+            f8_static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
                 const bool mrow = m0 + i * 16 < g.M;
-#pragma clang loop unroll(full)
-                for (int p = 0; p < 4; ++p) {
+                f8_static_for<0, 4>([&](auto pc) __attribute__((always_inline)) {
+                    constexpr int p = decltype(pc)::value;
                     asm volatile("" : "+a"(acc[i][2 * p]), "+a"(acc[i][2 * p + 1]));
                     const f32x4 lo = acc[i][2 * p], hi = acc[i][2 * p + 1];
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -311,20 +319,23 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
                     r0 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[2], a8[3], r0, true);
                     r1 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[4], a8[5], r1, false);
                     r1 = __builtin_amdgcn_cvt_pk_fp8_f32(a8[6], a8[7], r1, true);
-                    if (mrow && n + 32 * p < g.N) {
+                    const bool on = mrow && n + 32 * p < g.N;
+                    if (on) {
                         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-                        *(u32x2*)(qp0 + (long)(i * 16) * g.ldcq + 32 * p) = (u32x2){(uint32_t)r0, (uint32_t)r1};
-                        sw[i >> 2][p] |= (uint32_t)(e + 127) << (8 * (i & 3));
+                        *(u32x2*)(qp0 + (long)(i * 16) * ldcq + 32 * p) = (u32x2){(uint32_t)r0, (uint32_t)r1};
                     }
-                }
-            }
+                    const uint32_t bits = on ? (uint32_t)(e + 127) << (8 * (i & 3)) : 0u;
+                    if constexpr (i < 4) { if constexpr (p == 0) sw00 |= bits; else if constexpr (p == 1) sw01 |= bits; else if constexpr (p == 2) sw02 |= bits; else sw03 |= bits; }
+                    else { if constexpr (p == 0) sw10 |= bits; else if constexpr (p == 1) sw11 |= bits; else if constexpr (p == 2) sw12 |= bits; else sw13 |= bits; }
+                });
+            });
             const int t = tn * (TN / 128) + wc, RBo = f8_groups_dev(g.M);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const uint32_t wv = fq == 0 ? sw[a][0] : fq == 1 ? sw[a][1] : fq == 2 ? sw[a][2] : sw[a][3];
-                const int rb = tm * (TM / 64) + wr * 2 + a;
-                if (tn * TN + wc * 128 + 32 * fq < g.N && rb < RBo) g.SCq[(((long)t * RBo + rb) * 4 + fq) * 16 + fr] = wv;
-            }
+            const uint32_t wv0 = fq == 0 ? sw00 : fq == 1 ? sw01 : fq == 2 ? sw02 : sw03;      // selects on scalars: an array indexed by fq lives in scratch
+            const uint32_t wv1 = fq == 0 ? sw10 : fq == 1 ? sw11 : fq == 2 ? sw12 : sw13;
+            const bool col_ok = tn * TN + wc * 128 + 32 * fq < g.N;
+            const int rb0 = tm * (TM / 64) + wr * 2;
+            if (col_ok && rb0 < RBo) g.SCq[(((long)t * RBo + rb0) * 4 + fq) * 16 + fr] = wv0;
+            if (col_ok && rb0 + 1 < RBo) g.SCq[(((long)t * RBo + rb0 + 1) * 4 + fq) * 16 + fr] = wv1;
         };
         // full tile, bf16 output: the lean forms of gemm_bf16_wp_kernel (no bounds test, no select, no branch per chunk; with a residual, all 32
         // residual chunks of the lane requested in one burst into registers that are dead here and consumed behind ONE constant wait count:
@@ -410,6 +421,21 @@ __global__ __launch_bounds__(256, 1) void gemm_f8_wp_kernel(F8Args g) {
         else if (g.act == AV_ACT_GELU) run(std::integral_constant<int, AV_ACT_GELU>{});
         else if (g.act == AV_ACT_QUICK_GELU) run(std::integral_constant<int, AV_ACT_QUICK_GELU>{});
         else run(std::integral_constant<int, AV_ACT_SILU>{});
+        // The next K-step's operand fragments are read AGAIN here instead of being carried through the epilogue (the K loop loaded them in
+        // place during the tile's last K-step; their LDS buffer stays untouched until that K-step runs: its own DMA refills it): 128 registers
+        // the epilogue can use -- it spilled 26 - 57 of them otherwise, and every scratch reload between the tile's global stores is a
+        // compiler-made vmcnt(0), i.e. a wait for the stores' acknowledgements.  Unconditional ("=v" outputs: the old values are dead).
+        {
+            const int dx = bo ? STAGE : -STAGE;                       // ad[] already points at the other buffer: undo the last swap
+            const int a0 = ad[0] + dx, a1 = ad[1] + dx, b0 = ad[2] + dx, b1 = ad[3] + dx;
+#define F8_RE_A(I) F8_RD(FA[I].lo, a0, (I) * 2048); F8_RD(FA[I].hi, a1, (I) * 2048)
+#define F8_RE_B(J) F8_RD(FB[J].lo, b0, F8_BOFF(J)); F8_RD(FB[J].hi, b1, F8_BOFF(J))
+            F8_RE_B(0); F8_RE_B(1); F8_RE_B(2); F8_RE_B(3); F8_RE_B(4); F8_RE_B(5); F8_RE_B(6); F8_RE_B(7);
+            F8_RE_A(0); F8_RE_A(1); F8_RE_A(2); F8_RE_A(3); F8_RE_A(4); F8_RE_A(5); F8_RE_A(6); F8_RE_A(7);
+#undef F8_RE_A
+#undef F8_RE_B
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         // the next tile accumulates from zero (the K-step body has no "C = 0" variant, see f8_step)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
