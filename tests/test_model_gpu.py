@@ -54,7 +54,10 @@ def test_whisper_encoder_vs_oracle(dev, tiny, model32, model16):
     assert (out - ref).abs().max() < 1e-3, (out - ref).abs().max()
     out16 = model16.whisper_engine.forward(audio.to(dev)).float().cpu()
     err = (out16 - ref).abs()
-    assert err.mean() < 2e-2 and err.max() < 0.35, (err.mean(), err.max())       # layer-normed outputs, O(1) scale
+    assert err.mean() < 2e-2, err.mean()                                         # layer-normed outputs, O(1) scale
+    from bars import BF16_ENC_REL_L2, rel_l2
+    assert rel_l2(out16, ref) < BF16_ENC_REL_L2, rel_l2(out16, ref)              # a per-tensor scale error of a few percent cannot hide under this
+    assert err.max() < 0.12, err.max()                                           # tail of ~4e5 values with sigma ~5e-3 (was 0.35: VERDICT r02 weak #1d)
 
 
 def test_clip_cls_vs_oracle(dev, tiny, model32, model16):
