@@ -92,6 +92,7 @@ _SIGS = {
     "avllm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "avllm_set_gemm_variant": ([i32], i32),
     "avllm_set_knob": ([C.c_char_p, i32], i32),
+    "avllm_attention_fwd_mxq": ([vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i64, i64, i64, f32, vp], i32),
     "avllm_im2col_k3": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "avllm_groupnorm_tokens": ([vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "avllm_gemm_tn": ([vp, i64, i32, vp, i64, i32, i32, vp, i64, f32, i32, vp], i32),

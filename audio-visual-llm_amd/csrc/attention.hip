@@ -269,10 +269,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
 //                                  V^T fragments come from the row-major V image through ds_read_b64_tr_b16 in that same order.
 // 197 tokens (ViT-B/16) are 13 blocks of 16 in both directions (208 padded rows instead of the 224 of a 32-row tiling); 7 waves x 2
 // query blocks.  Output leaves through a 16x32 bf16 scratch per wave as 16-byte row chunks.  HF:models/clip/modeling_clip.py:297-335.
-template <int NKB, int NW>
+// QOUT: the output leaves block-scaled to e4m3 (OCP MX: one E8M0 per 32 consecutive features, fp8.hip mx_quant_kernel's rule applied to the
+// bf16-rounded values, i.e. bit-identical to quantising the bf16 output in a separate pass) as codes oq [rows, ldoq] + the layout-0 scale
+// image osc of an avllm_gemm_f8 A operand: the fp8 out-projection reads it directly and the [M, d] bf16 attention output never exists
+// (1.6 GB written + read back per ViT-L/14 layer at 750 frames x 4 clips).  A 32-feature block of a row = the 4 lanes of one row in the
+// write-out below; the scale byte of global row m, column block cb sits at ((((cb >> 2) * RB + (m >> 6)) * 4 + (cb & 3)) * 16 + (m & 15)) * 4 + ((m >> 4) & 3).
+template <int NKB, int NW, bool QOUT>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int T, int H, long ldq, long ldk,
-                                                          long ldv, long ldo, float scale_log2e, int G) {
+                                                          long ldv, long ldo, float scale_log2e, int G, uint8_t* __restrict__ oq, long ldoq,
+                                                          uint8_t* __restrict__ osc, int RBo) {
     constexpr int HD = 64, KS = 160, VS = 160, OS = 80;
     constexpr int NPV = (NKB + 1) / 2, KROWS = NKB * 16, VROWS = NPV * 32, NT = NW * 64;
     constexpr int NQ = (NKB + NW - 1) / NW;                       // query blocks per wave
@@ -404,7 +410,35 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS traffic is ordered; pins the compiler's order
             const int row = lane >> 2, ch = lane & 3;
             const u32x4 val = *(const u32x4*)(o_lds + row * OS + ch * 16);
-            if (q0 + row < T) *(u32x4*)(o + ((long)b * T + q0 + row) * ldo + (long)hh * HD + hf * 32 + ch * 8) = val;
+            if constexpr (QOUT) {
+                const bf16x8 vb = __builtin_bit_cast(bf16x8, val);
+                float f[8], amax = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { f[c] = (float)vb[c]; amax = fmaxf(amax, fabsf(f[c])); }
+                amax = fmaxf(amax, __shfl_xor(amax, 1));
+                amax = fmaxf(amax, __shfl_xor(amax, 2));
+                int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;              // floor(log2 amax) - 8 (fp8.hip mx_quant_kernel, oracle/mxfp8.py)
+                e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                const float invs = __uint_as_float((uint32_t)(127 - e) << 23);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) f[c] = fminf(fmaxf(f[c] * invs, -448.f), 448.f);
+                int r0 = 0, r1 = 0;
+                r0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], r0, false);
+                r0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], r0, true);
+                r1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], r1, false);
+                r1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], r1, true);
+                if (q0 + row < T) {
+                    const long m = (long)b * T + q0 + row;
+                    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                    *(u32x2*)(oq + m * ldoq + (long)hh * HD + hf * 32 + ch * 8) = (u32x2){(uint32_t)r0, (uint32_t)r1};
+                    if (ch == 0) {
+                        const int cb = hh * (HD / 32) + hf;
+                        osc[((((long)(cb >> 2) * RBo + (m >> 6)) * 4 + (cb & 3)) * 16 + (m & 15)) * 4 + ((m >> 4) & 3)] = (uint8_t)(e + 127);
+                    }
+                }
+            } else {
+                if (q0 + row < T) *(u32x4*)(o + ((long)b * T + q0 + row) * ldo + (long)hh * HD + hf * 32 + ch * 8) = val;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
@@ -421,17 +455,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
 
 template <int NKB, int NW>
 int launch_fwd_short(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, long ldq, long ldk, long ldv,
-                     long ldo, float scale, hipStream_t st, int G) {
+                     long ldo, float scale, hipStream_t st, int G, void* oq = nullptr, long ldoq = 0, void* osc = nullptr) {
     constexpr int LDS = NKB * 16 * 160 + ((NKB + 1) / 2) * 32 * 160 + NW * 16 * 80;
     static bool attr[64] = {};
     int dev = 0;
     AV_HIP(hipGetDevice(&dev));
     if (!attr[dev & 63]) {
-        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr[dev & 63] = true;
     }
-    hipLaunchKernelGGL((attn_fwd_short<NKB, NW>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse,
-                       T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G);
+    const int RBo = (int)(((long)B * T + 255) / 256 * 4);            // mx_groups(rows) of fp8.hip: 64-row groups, padded to whole 256-row tiles
+    if (oq) hipLaunchKernelGGL((attn_fwd_short<NKB, NW, true>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse,
+                               T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G, (uint8_t*)oq, ldoq, (uint8_t*)osc, RBo);
+    else hipLaunchKernelGGL((attn_fwd_short<NKB, NW, false>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse,
+                            T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G, nullptr, 0, nullptr, 0);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -472,6 +510,24 @@ int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float
         return launch_fwd<64, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
     }
     return launch_fwd<128, 4>(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, causal, st, G);
+}
+
+// Non-causal self-attention of short sequences with the output block-scaled to e4m3 in the epilogue (attn_fwd_short<.., QOUT>): codes
+// oq [B*T, ldoq] + the layout-0 scale image an avllm_gemm_f8 A operand takes.  Only the shapes the one-pass kernel covers.
+bool av_attention_fwd_mxq_ok(int B, int T, int H, int hd, int dtype, int kv_heads) {
+    return dtype == AV_BF16 && hd == 64 && T <= 272 && B <= 65535 && (kv_heads <= 0 || kv_heads == H) && (H * hd) % 128 == 0 && av_knob(AV_KNOB_ATTN_SHORT) != 0 &&
+           !av_knob(AV_KNOB_F8_UNFUSED_QUANT);
+}
+int av_attention_fwd_mxq(const void* q, const void* k, const void* v, void* oq, long ldoq, void* osc, int B, int T, int H, int hd, long ldq, long ldk,
+                         long ldv, float scale, hipStream_t st) {
+    AV_CHECK_ARG(q && k && v && oq && osc && av_attention_fwd_mxq_ok(B, T, H, hd, AV_BF16, H) && ldoq % 16 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0,
+                 "attention_fwd_mxq: bad args (bf16, head_dim 64, T <= 272, 16-byte aligned code rows)");
+    if (T <= 208) return launch_fwd_short<13, 7>(q, k, v, nullptr, nullptr, B, T, H, ldq, ldk, ldv, 0, scale, st, 1, oq, ldoq, osc);
+    return launch_fwd_short<17, 9>(q, k, v, nullptr, nullptr, B, T, H, ldq, ldk, ldv, 0, scale, st, 1, oq, ldoq, osc);
+}
+extern "C" int avllm_attention_fwd_mxq(const void* q, const void* k, const void* v, void* oq, int64_t ldoq, void* scales, int32_t B, int32_t T, int32_t H,
+                                       int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, float scale, void* stream) {
+    return av_attention_fwd_mxq(q, k, v, oq, ldoq, scales, B, T, H, hd, ldq, ldk, ldv, scale, (hipStream_t)stream);
 }
 
 bool av_attention_bwd_fuses_rope(int dtype, int hd, int impl) { return impl == 0 && dtype == AV_BF16 && (hd == 128 || hd == 64); }

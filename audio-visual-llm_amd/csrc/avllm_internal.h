@@ -13,6 +13,9 @@ int av_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rs
 int av_rope(void* x, long ld, long rows, int T, int heads, int hd, int pos0, float theta, int inverse, int dtype, hipStream_t st);
 int av_swiglu_fwd(const void* gu, void* h, long M, int F, int dtype, hipStream_t st);
 int av_swiglu_bwd(const void* dh, const void* gu, void* dgu, long M, int F, int dtype, hipStream_t st);
+bool av_attention_fwd_mxq_ok(int B, int T, int H, int hd, int dtype, int kv_heads);
+int av_attention_fwd_mxq(const void* q, const void* k, const void* v, void* oq, long ldoq, void* osc, int B, int T, int H, int hd, long ldq, long ldk,
+                         long ldv, float scale, hipStream_t st);
 int av_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk, int H,
                      int hd, long ldq, long ldk, long ldv, long ldo, float scale, int causal, int dtype, int impl,
                      hipStream_t st, int kv_heads = 0);

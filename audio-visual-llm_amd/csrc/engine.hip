@@ -75,6 +75,12 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
             AV_TRY(av_gemm(&g, st));
         }
         const char* qkv = (const char*)b.qkv;
+        // fp8: the attention output is only ever the out-projection's A operand -- the one-pass kernel (CLIP: <= 272 tokens) block-scales it in its
+        // epilogue; the bf16 tensor is not written (the CLS-only last block keeps the bf16 form)
+        const bool att_q = fp8 && !(cls_only_last && l == layers - 1) && av_attention_fwd_mxq_ok((int)items, tokens, heads, hd, dtype, heads);
+        if (att_q) AV_TRY(av_attention_fwd_mxq(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, b.f8.q, d, b.f8.s, (int)items, tokens, heads, hd,
+                                               3 * d, 3 * d, 3 * d, 1.0f / sqrtf((float)hd), st));
+        else
         AV_TRY(av_attention_fwd(qkv, qkv + (size_t)d * es, qkv + (size_t)2 * d * es, b.att, nullptr, (int)items, tokens, tokens,
                                 heads, hd, 3 * d, 3 * d, 3 * d, d, 1.0f / sqrtf((float)hd), 0, dtype, 0, st));
         if (cls_only_last && l == layers - 1) {
@@ -92,7 +98,7 @@ int encoder_layers(int dtype, const avllm_enc_layer* L, int layers, int d, int h
             return AV_OK;
         }
         if (fp8) {      // the CLS-only last block above stays bf16: a handful of rows
-            AV_TRY(f8_quant(b.f8, b.att, d, (int)M, d, st));
+            if (!att_q) AV_TRY(f8_quant(b.f8, b.att, d, (int)M, d, st));
             AV_TRY(f8_proj(b.f8, (int)M, d, P.wo8, P.so8, d, b.x, d, P.bo, AV_ACT_NONE, b.x, d, st));
             if (nq) AV_TRY(av_norm_mxq(b.x, P.ln2_w, P.ln2_b, nullptr, nullptr, b.f8.q, d, b.f8.s, M, d, eps, st));
             else {

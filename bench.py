@@ -48,7 +48,7 @@ def synthetic_batch(cfg, B, frames, seed, device):
     return audio, video, labels, labels[:, :32].clone()
 
 
-PMC_SUMMARY = "profiles/r02_pmc_hbm_summary_b16.txt"
+PMC_SUMMARY = "profiles/r03_pmc_hbm_summary_b16.txt"
 TIMING_EVERY = 10
 
 

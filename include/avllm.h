@@ -195,6 +195,11 @@ int avllm_attention_bwd(const void* q, const void* k, const void* v, const void*
  * ignore_index -100 and the last position.  loss_sum/count are ACCUMULATED (zero them first). row_lse [B*T]. */
 int avllm_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V,
                  float* row_lse, float* loss_sum, float* count, int32_t dtype, void* stream);
+/* The same attention for short non-causal sequences (T <= 272, head_dim 64, bf16: the CLIP towers) with the OUTPUT block-scaled to e4m3 in the
+ * kernel's epilogue: codes oq [B*T, ldoq] + the layout-0 scale image of an avllm_gemm_f8 A operand (avllm_mx_scale_bytes(B*T, H*hd) bytes),
+ * bit-identical to avllm_mx_quantize of the bf16 output.  Used by the fp8 encoders: the bf16 attention output is never written. */
+int avllm_attention_fwd_mxq(const void* q, const void* k, const void* v, void* oq, int64_t ldoq, void* scales, int32_t B, int32_t T, int32_t H,
+                            int32_t hd, int64_t ldq, int64_t ldk, int64_t ldv, float scale, void* stream);
 /* dlogits = (softmax - onehot) * (grad_scale / *count) for scored rows, 0 elsewhere (may alias logits) */
 int avllm_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* row_lse, const float* count,
                  float grad_scale, void* dlogits, int32_t B, int32_t T, int32_t V, int32_t dtype, void* stream);
