@@ -117,6 +117,20 @@ def attention_fwd(qkv, B, T, H, hd, causal, scale=None, impl=0, want_lse=True, k
     return o, lse
 
 
+def attention_fwd_mxq(qkv, B, T, H, hd, scale=None):
+    """Short non-causal self-attention (T <= 272, hd 64, bf16) with the output block-scaled to e4m3 in the kernel's epilogue:
+    qkv [B*T, 3*H*hd] -> (codes uint8 [B*T, H*hd], layout-0 scale image) == mx_quantize(attention_fwd(...)[0], 0) bit for bit."""
+    lib = L.load()
+    d = H * hd
+    q = torch.empty(B * T, d, device=qkv.device, dtype=torch.uint8)
+    s = torch.zeros(lib.avllm_mx_scale_bytes(B * T, d), device=qkv.device, dtype=torch.uint8)
+    es = qkv.element_size()
+    p = L.ptr(qkv)
+    L.check(lib.avllm_attention_fwd_mxq(p, p + d * es, p + 2 * d * es, L.ptr(q), d, L.ptr(s), B, T, H, hd, _ld(qkv), _ld(qkv), _ld(qkv),
+                                        float(hd ** -0.5 if scale is None else scale), L.stream_ptr()))
+    return q, s
+
+
 def attention_bwd(qkv, o, dout, lse, B, T, H, hd, causal, scale=None, impl=0, kv_heads=None):
     d = H * hd
     dkv = (kv_heads or H) * hd

@@ -211,11 +211,14 @@ def config5_leg(dev, steps=4, B=4, frames=750):
     cfg = model.cfg
     batch = synthetic_batch(cfg, B, frames, 4321, dev)
     engines = [model.whisper_engine, model.clip_engine, model.llm_engine]
+    lora0 = model.llm_engine.lora_p.clone()             # both arithmetics start from the same adapters (final_loss is then comparable)
     out = {"workload": f"BASELINE configs[4]: whisper-large-v3 + clip-vit-large-patch14 -> Mistral-7B lora r16, synthetic {frames / 25:g} s clips ({frames} frames), "
                        f"per_gpu_batch {B}, max_seq_len 512, train seq 256", "steps": steps, "warmup": 2}
     for mode in ("bf16", "fp8"):
         for e in engines:
             e.desc.fp8 = int(mode == "fp8")
+        model.llm_engine.lora_p.copy_(lora0)
+        model.llm_engine.pack_lora()
         tr = ClipWhisperTrainer(model, learning_rate=5e-5, weight_decay=0.01, grad_clip=0.5, total_steps=1000, use_graph=True)
         for _ in range(2):
             tr.train_step(*batch)

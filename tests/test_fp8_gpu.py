@@ -142,6 +142,22 @@ def test_model_fp8_train_step_vs_fake_quant_oracle(dev, golden_dir):
     assert all(np.isfinite(losses)) and not torch.equal(p0, m.llm_engine.lora_p) and losses[-1] < losses[0] + 0.05
 
 
+@pytest.mark.parametrize("T,H,B", [(197, 12, 5), (257, 16, 7), (50, 4, 3), (272, 2, 2)])
+def test_short_attention_with_mx_quantised_output_is_bit_identical_to_the_separate_pass(dev, T, H, B):
+    """The fp8 encoders take the attention output as e4m3 codes + scale image straight from the attention kernel's epilogue
+    (avllm_attention_fwd_mxq); it must equal avllm_mx_quantize applied to the bf16 attention output BIT FOR BIT -- codes, and every scale byte
+    (rows of different frames share scale words: the byte addressing by global row is what this pins)."""
+    from avllm import ops
+    d = H * 64
+    qkv = rnd(B * T, 3 * d, dtype=torch.bfloat16, seed=70 + T)
+    o, _ = ops.attention_fwd(qkv, B, T, H, 64, causal=False, want_lse=False)
+    q_ref, s_ref = ops.mx_quantize(o, 0)
+    q, s = ops.attention_fwd_mxq(qkv, B, T, H, 64)
+    assert torch.equal(q, q_ref), int((q != q_ref).sum())
+    assert torch.equal(s, s_ref), int((s != s_ref).sum())
+    assert int(s.max()) > 100 and int((q != 0).sum()) > q.numel() // 2          # not vacuous
+
+
 def test_config5_family_whole_fp8_step_vs_fake_quant_oracle__mx_rule_parity_unpinned(dev):
     """BASELINE configs[4] AS ONE MODEL at test size and realistic width: a 128-mel Whisper (large-v3 layout), a patch-14 CLIP on 224-pixel
     frames (257 tokens per frame: the ViT-L/14 sequence), a grouped-query LLM (Mistral layout: 8 query / 2 key-value heads), every width 1024,
