@@ -51,6 +51,7 @@ class LlamaCfg:
     eps: float = 1e-5
     theta: float = 10000.0
     kv_heads: int = 0           # grouped-query attention: key/value heads (0 = heads)
+    rope_scaling: tuple = ()    # () = plain RoPE; (factor, low_freq_factor, high_freq_factor, original_max_position_embeddings) = "llama3" scaling
 
     @property
     def head_dim(self):
@@ -207,15 +208,24 @@ def _cfg_from_hf_dir(path, kind):
         v = c.get("vision_config", c)
         return ClipCfg(v["hidden_size"], v["num_attention_heads"], v["num_hidden_layers"], v["intermediate_size"],
                        v.get("image_size", 224), v["patch_size"], v.get("layer_norm_eps", 1e-5))
-    scaling = c.get("rope_scaling") or (c.get("rope_parameters") or {})
-    if scaling.get("rope_type", scaling.get("type", "default")) not in ("default", None):
-        raise NotImplementedError(f"rope scaling '{scaling.get('rope_type', scaling.get('type'))}' (Llama-3.1 style) is not implemented: plain RoPE only")
+    rs = _rope_scaling(c.get("rope_scaling") or (c.get("rope_parameters") or {}))
     if c.get("head_dim") not in (None, c["hidden_size"] // c["num_attention_heads"]):
         raise NotImplementedError("head_dim != hidden_size / num_attention_heads is not implemented")
     rope = c.get("rope_theta", (c.get("rope_parameters") or {}).get("rope_theta", 10000.0))
     kvh = c.get("num_key_value_heads", c["num_attention_heads"])
     return LlamaCfg(c["hidden_size"], c["num_attention_heads"], c["num_hidden_layers"], c["intermediate_size"], c["vocab_size"],
-                    c.get("rms_norm_eps", 1e-5), rope, 0 if kvh == c["num_attention_heads"] else kvh)
+                    c.get("rms_norm_eps", 1e-5), rope, 0 if kvh == c["num_attention_heads"] else kvh, rs)
+
+
+def _rope_scaling(scaling):
+    """config.json `rope_scaling` -> LlamaCfg.rope_scaling.  "llama3" (Llama-3.1 / 3.2, e.g. the reference decode.py's default
+    checkpoints/Llama-3.2-1B) is implemented; other kinds (linear, dynamic, yarn, longrope) are refused."""
+    kind = scaling.get("rope_type", scaling.get("type", "default")) if scaling else "default"
+    if kind in ("default", None):
+        return ()
+    if kind == "llama3":
+        return (float(scaling["factor"]), float(scaling["low_freq_factor"]), float(scaling["high_freq_factor"]), int(scaling["original_max_position_embeddings"]))
+    raise NotImplementedError(f"rope scaling '{kind}' is not implemented: plain RoPE and the llama3 rule only")
 
 
 def weights_from_reference_state_dict(sd):
@@ -271,7 +281,8 @@ def resolve_arch(llm_path, whisper_model, clip_model, config, weights, seed, lor
                     kvh = getattr(hc, "num_key_value_heads", None) or hc.num_attention_heads
                     rope = getattr(hc, "rope_theta", None) or (getattr(hc, "rope_parameters", None) or {}).get("rope_theta", 10000.0)
                     parts[kind] = LlamaCfg(hc.hidden_size, hc.num_attention_heads, hc.num_hidden_layers, hc.intermediate_size,
-                                           hc.vocab_size, hc.rms_norm_eps, rope, 0 if kvh == hc.num_attention_heads else kvh)
+                                           hc.vocab_size, hc.rms_norm_eps, rope, 0 if kvh == hc.num_attention_heads else kvh,
+                                           _rope_scaling(getattr(hc, "rope_scaling", None) or {}))
             elif isinstance(path, str) and os.path.isdir(path) and os.path.exists(os.path.join(path, "config.json")):
                 parts[kind] = _cfg_from_hf_dir(path, kind)
             else:

@@ -207,6 +207,9 @@ class LlamaEngine:
         self.dkv = kvh * (d // cfg.heads)
         self.douts = (d, self.dkv, self.dkv, d)                  # output width of q, k, v, o (grouped-query: k/v are narrower)
         m.eps, m.theta, m.lora_scale = cfg.eps, cfg.theta, (lora_cfg.scale if self.use_lora else 0.0)
+        rs = tuple(getattr(cfg, "rope_scaling", ()) or ())
+        if rs:                                                   # Llama-3.1 / 3.2 "llama3" RoPE frequency scaling (include/avllm.h)
+            m.rope_factor, m.rope_low_freq_factor, m.rope_high_freq_factor, m.rope_orig_ctx = float(rs[0]), float(rs[1]), float(rs[2]), int(rs[3])
 
         def put(val):
             dv = _dev(val, dtype, device)

@@ -59,7 +59,8 @@ class Llama(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "d", "heads", "layers", "ffn", "vocab", "lora_r", "kv_heads")] + \
                [(n, f32) for n in ("eps", "theta", "lora_scale", "lora_dropout")] + [("dropout_seed", C.c_uint32)] + \
                [(n, vp) for n in ("dropout_seed_dev", "embed", "norm_w", "lm_head", "lm_head_t")] + [("layer", C.POINTER(LlamaLayer))] + \
-               [("fp8", i32), ("lm_head8", vp), ("slm_head8", vp)]
+               [("fp8", i32), ("lm_head8", vp), ("slm_head8", vp)] + \
+               [(n, f32) for n in ("rope_factor", "rope_low_freq_factor", "rope_high_freq_factor")] + [("rope_orig_ctx", i32)]
 
 
 class GemmF8Desc(C.Structure):

@@ -61,7 +61,8 @@ int av_gemm_tn_multi(const void* Big, long ldb, int NB, const void* const* Small
                      const uint32_t* seed_dev, int shared, int dtype, hipStream_t st);
 bool av_dec_proj_supported(int dtype, int M, int K, int N, int mode, int hd);
 int av_dec_proj(const avllm_dec_proj_desc* d, hipStream_t st);
-int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev = nullptr);
+struct AvRopeScale { float factor = 1.f, low_freq_factor = 1.f, high_freq_factor = 4.f; int orig_ctx = 0; };      // orig_ctx == 0: plain RoPE
+int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev = nullptr, AvRopeScale sc = AvRopeScale());
 int av_rope_tab(void* x, long ld, long rows, int T, int heads, int hd, const float* tab, int inverse, int dtype, hipStream_t st);
 int av_dropout(const void* x, void* y, long rows, int d, uint32_t seed, float p, int dtype, hipStream_t st, const uint32_t* seed_dev = nullptr);
 bool av_lora_dx_masked_supported(int dtype, int N, int r, const long* ldt, const long* ldat, int nj, long ldr, long ldo);

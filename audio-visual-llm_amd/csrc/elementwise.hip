@@ -36,13 +36,24 @@ __global__ void rope_kernel(T* __restrict__ x, long ld, long rows, int T_, int h
 }
 
 // cos/sin table [T][hd/2][2] for positions pos0..pos0+T-1 (computed once per call instead of per element per layer)
-__global__ void rope_table_kernel(float* __restrict__ tab, int T_, int hd, int pos0, float theta, const int* __restrict__ pos_dev) {
+// sc.orig_ctx > 0: Llama-3.1 / 3.2 "llama3" frequency scaling (HF:modeling_rope_utils.py _compute_llama3_parameters): wavelengths beyond
+// orig_ctx / low_freq_factor are stretched by `factor`, those below orig_ctx / high_freq_factor kept, the band between interpolated.
+__global__ void rope_table_kernel(float* __restrict__ tab, int T_, int hd, int pos0, float theta, const int* __restrict__ pos_dev, AvRopeScale sc) {
     const int half = hd >> 1;
     if (pos_dev) pos0 += *pos_dev;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T_ * half) return;
     const int i = idx % half, t = idx / half;
-    const float inv = 1.0f / powf(theta, (float)(2 * i) / (float)hd);
+    float inv = 1.0f / powf(theta, (float)(2 * i) / (float)hd);
+    if (sc.orig_ctx > 0) {
+        const float wavelen = 6.283185307179586f / inv, octx = (float)sc.orig_ctx;
+        const float low_wl = octx / sc.low_freq_factor, high_wl = octx / sc.high_freq_factor;
+        if (wavelen > low_wl) inv = inv / sc.factor;
+        else if (!(wavelen < high_wl)) {
+            const float smooth = (octx / wavelen - sc.low_freq_factor) / (sc.high_freq_factor - sc.low_freq_factor);
+            inv = (1.0f - smooth) * inv / sc.factor + smooth * inv;
+        }
+    }
     const float ang = (float)(pos0 + t) * inv;
     tab[2 * idx] = cosf(ang);
     tab[2 * idx + 1] = sinf(ang);
@@ -379,9 +390,9 @@ int av_rope(void* x, long ld, long rows, int T, int heads, int hd, int pos0, flo
     return AV_OK;
 }
 
-int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev) {
+int av_rope_table(float* tab, int T, int hd, int pos0, float theta, hipStream_t st, const int* pos_dev, AvRopeScale sc) {
     AV_CHECK_ARG(tab && T > 0 && hd % 8 == 0, "rope_table: bad args");
-    hipLaunchKernelGGL(rope_table_kernel, dim3(av_cdiv((long)T * (hd / 2), 256)), dim3(256), 0, st, tab, T, hd, pos0, theta, pos_dev);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(av_cdiv((long)T * (hd / 2), 256)), dim3(256), 0, st, tab, T, hd, pos0, theta, pos_dev, sc);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -31,6 +31,12 @@ inline avllm_gemm_desc gemm_desc(int dtype, const void* A, long lda, const void*
     return g;
 }
 
+inline AvRopeScale llama_rope_scale(const avllm_llama* m) {
+    AvRopeScale sc;
+    sc.factor = m->rope_factor; sc.low_freq_factor = m->rope_low_freq_factor; sc.high_freq_factor = m->rope_high_freq_factor; sc.orig_ctx = m->rope_orig_ctx;
+    return sc;
+}
+
 // ------------------------------------------------------------------ block-scaled fp8 projections (BASELINE config 5)
 // Scratch for the quantised activation of one projection input: codes [M, Kmax] + its scale image.  One quantisation serves every
 // projection that reads the same input (q, k and v of a decoder layer).
@@ -371,7 +377,7 @@ extern "C" int avllm_llama_lora_fwd_loss(const avllm_llama* m, const void* x, co
     const size_t es = av_dtype_size(dt);
     const int M = B * S;
     AV_HIP(hipMemcpyAsync(resid[0], x, (size_t)M * d * es, hipMemcpyDeviceToDevice, st));
-    AV_TRY(av_rope_table(w.rope_tab, S, hd, 0, m->theta, st));
+    AV_TRY(av_rope_table(w.rope_tab, S, hd, 0, m->theta, st, nullptr, llama_rope_scale(m)));
     const bool drop = m->lora_dropout > 0.f;
     // bf16 (MFMA kernels): masks are generated inside the rank-side GEMMs; fp32 parity mode materialises dropout(x)
     const bool fuse_drop = drop && m->dtype == AV_BF16 && d % 256 == 0 && m->lora_r <= 16;
@@ -651,7 +657,7 @@ int llama_infer_layer(const avllm_llama* m, int l, LlamaInferWs& w, int B, int S
         AV_TRY(lora_proj(m, w.xn, d, (const char*)P.wqkv + (size_t)llama_off(m, j) * d * es, d, d, llama_wid(m, j), P.lora[j], w.t, AVLLM_LORA_PAD,
                          (char*)w.qkv + (size_t)llama_off(m, j) * es, qw, nullptr, 0, M, st));
     char* qkv = (char*)w.qkv;
-    if (l == 0) AV_TRY(av_rope_table(w.rope_tab, S, hd, pos0, m->theta, st));
+    if (l == 0) AV_TRY(av_rope_table(w.rope_tab, S, hd, pos0, m->theta, st, nullptr, llama_rope_scale(m)));
     AV_TRY(av_rope_tab(qkv, qw, M, S, H + Hkv, hd, w.rope_tab, 0, dt, st));
     AV_TRY(av_kv_append(qkv + (size_t)d * es, qkv + (size_t)(d + dkv) * es, qw, kcl, vcl, B, S, pos0, Tmax, dkv, dt, st));
     const float scale = 1.0f / sqrtf((float)hd);
@@ -785,7 +791,7 @@ extern "C" int avllm_llama_decode_step_at(const avllm_llama* m, const int64_t* i
     const int dt = m->dtype, d = m->d;
     AV_TRY(av_embedding(m->embed, ids, w.x, B, d, dt, st));
     if (llama_decode_fused_ok(m, B)) {
-        AV_TRY(av_rope_table(w.rope_tab, 1, d / m->heads, pos, m->theta, st, pos_dev));
+        AV_TRY(av_rope_table(w.rope_tab, 1, d / m->heads, pos, m->theta, st, pos_dev, llama_rope_scale(m)));
         for (int l = 0; l < m->layers; ++l) AV_TRY(llama_decode_layer_fused(m, l, w, B, pos, pos_dev, kcache, vcache, Tmax, st));
         if (av_dec_proj_supported(AV_BF16, B, d, m->vocab, 0, 0)) {          // final norm folded into the lm_head stream
             avllm_dec_proj_desc p = {};

@@ -379,6 +379,10 @@ typedef struct avllm_llama {
                                       * the block-scaled fp8 matrix pipe (BASELINE config 5); LoRA terms, attention, norms and the whole
                                       * backward pass stay bf16 */
     const void *lm_head8, *slm_head8;
+    /* rope_orig_ctx > 0: "llama3" RoPE frequency scaling of Llama-3.1 / 3.2 checkpoints (config.json rope_scaling: factor, low_freq_factor,
+     * high_freq_factor, original_max_position_embeddings; HF:modeling_rope_utils.py _compute_llama3_parameters).  0 = plain RoPE. */
+    float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+    int32_t rope_orig_ctx;
 } avllm_llama;
 
 size_t avllm_llama_train_workspace_bytes(const avllm_llama* m, int32_t B, int32_t S);

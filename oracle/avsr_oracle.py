@@ -308,9 +308,18 @@ def rms_norm(x, w, eps):
     return w * (x * torch.rsqrt(var + eps))
 
 
-def rope_cos_sin(positions, hd, theta):
-    """HF:models/llama/modeling_llama.py:70-126 (default rope)."""
+def rope_cos_sin(positions, hd, theta, scaling=()):
+    """HF:models/llama/modeling_llama.py:70-126 (default rope); `scaling` = (factor, low_freq_factor, high_freq_factor,
+    original_max_position_embeddings) applies the "llama3" rule of HF:modeling_rope_utils.py _compute_llama3_parameters (Llama-3.1 / 3.2)."""
     inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    if scaling:
+        factor, low, high, octx = scaling
+        wavelen = 2 * math.pi / inv
+        inv_l = torch.where(wavelen > octx / low, inv / factor, inv)
+        smooth = (octx / wavelen - low) / (high - low)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        medium = ~(wavelen < octx / high) & ~(wavelen > octx / low)
+        inv = torch.where(medium, smoothed, inv_l)
     fr = positions.float()[:, None] * inv[None, :]
     emb = torch.cat([fr, fr], dim=-1)
     return emb.cos(), emb.sin()
@@ -339,7 +348,7 @@ def llama_hidden(sd, lora, c, lc, x, past=None, pos0=0, masks=None):
     x [B,T,d] inputs_embeds.  `past` = optional list of (k,v) per layer (KV cache), updated in place."""
     B, T, d = x.shape
     H, hd = c.heads, c.head_dim
-    cos, sin = rope_cos_sin(torch.arange(pos0, pos0 + T), hd, c.theta)
+    cos, sin = rope_cos_sin(torch.arange(pos0, pos0 + T), hd, c.theta, tuple(getattr(c, "rope_scaling", ()) or ()))
     scale = lc.scale if lc is not None else 0.0
     for i in range(c.layers):
         L = f"model.layers.{i}."

@@ -54,6 +54,7 @@ class LlamaCfg:
     eps: float = 1e-5
     theta: float = 10000.0
     kv_heads: int = 0           # grouped-query attention: key/value heads (0 = heads)
+    rope_scaling: tuple = ()    # () = plain RoPE; (factor, low_freq_factor, high_freq_factor, original_max_position_embeddings) = "llama3" rule
 
     @property
     def head_dim(self) -> int:

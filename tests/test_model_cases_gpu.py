@@ -178,6 +178,34 @@ def test_config5_family_geometry_vs_oracle(dev):
     assert err.max() < 6e-2 and err.mean() < 1e-2 and abs(float(o16["loss"].detach()) - float(ref_loss)) < 2e-2
 
 
+def test_llama3_rope_scaling_train_and_generate_vs_oracle(dev):
+    """Llama-3.1 / 3.2 checkpoints carry `rope_scaling: {rope_type: llama3, ...}` (the reference's decode.py defaults to Llama-3.2-1B): the
+    frequency rule lives in the cos/sin table every RoPE consumer of the engine reads (training forward, the attention backward's fused
+    inverse rotation, prefill, the fused token step).  A grouped-query model with a small original context (so that most frequencies are
+    stretched or interpolated inside 256 positions): whole train step vs the oracle at the fp32 bars, greedy tokens identical, and a
+    negative control -- the same weights WITHOUT the rule differ by far more than the bar.  The oracle's rule is pinned against
+    transformers in tests/test_oracle.py."""
+    oc = Wt.tiny()
+    rs = (8.0, 1.0, 4.0, 64)
+    oc.llama = Wt.LlamaCfg(hidden=256, heads=4, layers=2, ffn=512, vocab=256, kv_heads=2, theta=500000.0, rope_scaling=rs)
+    W = Wt.all_weights(oc, 23, lora_b_std=0.05)
+    audio, video, labels, prompt = batch(oc, 2, 3, seed=12)
+    m = make_model(oc, W, "fp32")
+    assert m.llm_engine.desc.rope_orig_ctx == 64 and abs(m.llm_engine.desc.rope_factor - 8.0) < 1e-6
+    check_train(dev, oc, W, m, audio, video, prompt, labels, 512)
+    cfg = copy.copy(oc); cfg.max_seq_len = 256
+    m.max_seq_len = 256
+    ids = m.eval().generate(audio=audio.to(dev), video=video.to(dev), max_new_tokens=10).cpu()
+    ref = O.generate(W, cfg, audio, video, None, max_new_tokens=10, eos_token_id=m.eos_token_id)
+    assert torch.equal(ids, ref), (ids, ref)
+    # negative control: plain RoPE on the same weights
+    plain = copy.copy(oc); plain.llama = Wt.LlamaCfg(**{**vars(oc.llama), "rope_scaling": ()}); plain.max_seq_len = 512
+    _, logits_plain, _ = O.train_step_grads(W, plain, audio, video, prompt, labels)
+    cfg512 = copy.copy(oc); cfg512.max_seq_len = 512
+    _, logits_scaled, _ = O.train_step_grads(W, cfg512, audio, video, prompt, labels)
+    assert (logits_plain - logits_scaled).abs().max() > 2e-2
+
+
 def test_same_seed_same_model(dev):
     """Offline (synthetic) construction is a pure function of `seed`, connectors included (the reference draws its connector init from the
     global RNG): two builds agree bit for bit whatever the global RNG state, a different seed gives a different model."""

@@ -177,3 +177,26 @@ def test_connector_restatements_match_reference_fixture(golden_dir):
         sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
         y = fn(sd, torch.from_numpy(g[tag + ".x"]))
         assert y.shape == g[tag + ".y"].shape and (y - torch.from_numpy(g[tag + ".y"])).abs().max() < 5e-5, tag
+
+
+def test_llama3_rope_scaling_matches_transformers():
+    """The oracle's "llama3" RoPE frequency rule (Llama-3.1 / 3.2: the reference decode.py's default LLM is checkpoints/Llama-3.2-1B) against
+    transformers' own ROPE_INIT_FUNCTIONS["llama3"] on Llama-3.2-1B's published rope_scaling values."""
+    from transformers import LlamaConfig
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    rs = {"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+    try:
+        cfg = LlamaConfig(hidden_size=2048, num_attention_heads=32, num_hidden_layers=1, intermediate_size=64, vocab_size=64, rope_theta=500000.0,
+                          rope_scaling=dict(rs), max_position_embeddings=131072)
+    except TypeError:
+        cfg = LlamaConfig(hidden_size=2048, num_attention_heads=32, num_hidden_layers=1, intermediate_size=64, vocab_size=64,
+                          rope_parameters=dict(rs, rope_theta=500000.0), max_position_embeddings=131072)
+    inv_hf, att = ROPE_INIT_FUNCTIONS["llama3"](cfg, "cpu")
+    assert att == 1.0
+    pos = torch.tensor([0, 1, 77, 255, 5000])
+    cos, sin = O.rope_cos_sin(pos, 64, 500000.0, (32.0, 1.0, 4.0, 8192))
+    fr = pos.float()[:, None] * inv_hf.float()[None, :]
+    ref = torch.cat([fr, fr], -1)
+    assert (cos - ref.cos()).abs().max() < 1e-5 and (sin - ref.sin()).abs().max() < 1e-5
+    plain_cos, _ = O.rope_cos_sin(pos, 64, 500000.0)
+    assert (cos - plain_cos).abs().max() > 0.1                    # the rule is not a no-op on these positions
