@@ -30,6 +30,7 @@ namespace {
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+__device__ __forceinline__ float max3f(float a, float x, float y) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, x), y); }
 
 template <int HD, int NW, bool CAUSAL>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
@@ -164,16 +165,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
                 s1[i] = (two && key0 + 32 <= klim) ? s1[i] : -INFINITY;
             }
         }
-        // v_max3_f32 written out: fmaxf canonicalises each operand with a v_max x, x first (three instructions per two scores instead of one)
+        // IEEE-2019 maximum (v_maximum3_f32 on gfx950): fmaxf canonicalises each operand with a v_max x, x first (three instructions per two
+        // scores instead of one).  It has to stay a builtin: the scores are MFMA results, and the compiler pads the MFMA -> VALU read hazard
+        // only for instructions it can see (an inline-asm v_max3 here read scores before the matrix pipe had written them).
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(mloc), "v"(s0[i]), "v"(s1[i]));
-        {
-            const float other = __shfl_xor(mloc, 32);
-            asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(mloc), "v"(other));
-        }
+        for (int i = 0; i < 16; ++i) mloc = max3f(mloc, s0[i], s1[i]);
+        mloc = __builtin_elementwise_maximum(mloc, __shfl_xor(mloc, 32));
         mloc *= scale_log2e;
-        float m_new;
-        asm("v_max_f32 %0, %1, %2" : "=v"(m_new) : "v"(m_run), "v"(mloc));
+        const float m_new = __builtin_elementwise_maximum(m_run, mloc);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         float psum = 0.f;
@@ -326,14 +325,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, g = lane >> 4;
-    // The kernel is bound by its instruction stream (profiles/r02_experiments.txt), so the per-score work is trimmed: v_max3_f32 written out
-    // (fmaxf canonicalises every operand with a v_max x, x first: three instructions per two scores instead of one), and a FULL form for
+    // The kernel is bound by its instruction stream (profiles/r02_experiments.txt), so the per-score work is trimmed: v_maximum3_f32 through
+    // max3f (fmaxf canonicalises every operand with a v_max x, x first: three instructions per two scores instead of one), and a FULL form for
     // sequences that use every key block (CLIP: 197 tokens = 13 blocks) without the per-block "is this block inside T" branches.
-    auto max3 = [](float a, float x, float y) __attribute__((always_inline)) {
-        float r;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(x), "v"(y));
-        return r;
-    };
+    auto max3 = [](float a, float x, float y) __attribute__((always_inline)) { return max3f(a, x, y); };
     auto qblock = [&](int qi, auto fullc) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(fullc)::value;             // nkb == NKB
         const int qb = w + NW * qi;

@@ -106,6 +106,7 @@ def test_batched_and_unbatched_steps_agree(dev, monkeypatch):
         out["loss"].backward()
         res[mode] = (float(out["loss"].detach()), eng.lora_g.clone())
     Lk.check(Lk.load().avllm_set_knob(b"LORA_UNBATCHED", 0))
-    assert abs(res["batched"][0] - res["unbatched"][0]) < 1e-6
+    # the loss is a float atomicAdd over ~80 rows (sum ~ 480, fp32 ulp 3e-5): the order of the adds moves the mean by a few 1e-7 from launch to launch
+    assert abs(res["batched"][0] - res["unbatched"][0]) < 1e-5
     assert rel_l2(res["batched"][1], res["unbatched"][1]) < 1e-4
     assert float(res["batched"][1].abs().max()) > 0
