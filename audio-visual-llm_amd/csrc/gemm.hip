@@ -783,13 +783,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         int tm, tn;
         tile_coords(tile_id(vid), tiles_m, tiles_n, tm, tn, !(g.dbg & 4), g.gw);
         lm0 = tm * HBM_; ln0 = tn * HBN_;
-        const unsigned la2 = (unsigned)g.lda * 2, lb2 = (unsigned)g.ldb * 2, ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
+        const unsigned la2 = (unsigned)g.lda * 2, lb2 = (unsigned)g.ldb * 2;
+        unsigned ma = g.e.M - 1 - lm0, mb = g.e.N - 1 - ln0;
+        if (g.dbg & 0x20000) { ma = ma < 63 ? ma : 63; mb = mb < 63 ? mb : 63; }      // ... only the tile's first 64 rows: TCP misses that hit in L2
+        if (g.dbg & 0x10000) { ma = 0; mb = 0; }                     // experiment builds: every lane fetches row 0 (always a cache hit): the memory path out of the picture
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const unsigned r = r0 + q * 8;
             vA1[q] = __umul24(r < ma ? r : ma, la2) + ch; vB1[q] = __umul24(r < mb ? r : mb, lb2) + ((q & 1) ? chB1 : chB0);
         }
         tA1 = g.A + (long)lm0 * g.lda; tB1 = g.B + (long)ln0 * g.ldb;
+        if (g.dbg & 0x40000) { tA1 = g.A; tB1 = g.B; }                 // experiment builds: every tile multiplies the first 256 rows of both operands (every line a TCP miss and, for short K, an L2 hit)
     };
     auto advance = [&]() __attribute__((always_inline)) {            // after K-step lt of the context tile has been issued
         if (++lt < nt) return;
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
     {   // experiment: de-phase the workgroups (all tiles take the same time, so the whole grid otherwise reaches its epilogue store burst at once)
         // measured (tools/gemm_epi_experiment.sh, clip qkv 394000x2304x768): 1448 us in lockstep, 1292 us with two phases (4 or 8: the same);
         // a one-round launch only pays the delay, hence >= 6 rounds.  dbg bits 4.. override the phase count (1 = off)
-        const int phases = (g.dbg >> 4) ? (g.dbg >> 4) : (ntiles >= 6 * G ? 2 : 1);
+        const int phases = ((g.dbg >> 4) & 0xff) ? ((g.dbg >> 4) & 0xff) : (ntiles >= 6 * G ? 2 : 1);
         if (phases > 1) {
             const int ph = (blockIdx.x >> 3) % phases;
             const int n = ph * (nt * 2100 + 11000) / (phases * 6400);
@@ -926,6 +930,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         auto run_full = [&](auto actc, auto hasbc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(actc)::value;
             constexpr bool HASB = decltype(hasbc)::value;
+#ifdef AVLLM_EXPERIMENT_KNOBS
+            u32x4 fold = {0u, 0u, 0u, 0u};
+#endif
 #pragma clang loop unroll(full)
             for (int i = 0; i < 8; ++i) {
                 bf16* const cpi = cp0 + (long)(i * 16) * ldc;
@@ -944,6 +951,29 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) v[c] = act_apply_fast(v[c], ACT);
                     }
+#ifdef AVLLM_EXPERIMENT_KNOBS
+                    {   // store cache-policy experiment (bits 20..22 of GEMM_DBG): 1 = non-temporal builtin, 2.. = explicit policy bits
+                        const int sm = (g.dbg >> 20) & 7;
+                        if (sm) {
+                            bf16x8 t;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) t[c] = (bf16)v[c];
+                            const u32x4 tv = __builtin_bit_cast(u32x4, t);
+                            bf16* sp = cpi + 32 * p;
+                            if (sm == 1) __builtin_nontemporal_store(t, (bf16x8*)sp);
+                            else if (sm == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(sp), "v"(tv) : "memory");
+                            else if (sm == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(sp), "v"(tv) : "memory");
+                            else if (sm == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(sp), "v"(tv) : "memory");
+                            else if (sm == 5) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(sp), "v"(tv) : "memory");
+                            else if (sm == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(sp), "v"(tv) : "memory");
+                            else {                                   // 7: all of the epilogue's arithmetic, ONE store per lane and tile (the folded chunks)
+                                fold[0] ^= tv[0]; fold[1] ^= tv[1]; fold[2] ^= tv[2]; fold[3] ^= tv[3];
+                                if (i == 7 && p == 3) *(u32x4*)sp = fold;
+                            }
+                            continue;
+                        }
+                    }
+#endif
                     store_f<8>(cpi + 32 * p, v);
                 }
             }
@@ -1005,6 +1035,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_wp_kernel(GemmArgs g) {
         const std::true_type yes{};
         const std::false_type no{};
         const bool hb = g.e.bias != nullptr;
+#ifdef AVLLM_EXPERIMENT_KNOBS
+        if (g.dbg & 0x80000) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // experiment: no operand load in flight while the epilogue stores
+#endif
         if (full && !g.e.R && g.e.act == AV_ACT_NONE && !hb) run_full(std::integral_constant<int, AV_ACT_NONE>{}, no);           // Llama projections, gradient GEMMs
         else if (full && !g.e.R && g.e.act == AV_ACT_NONE && hb) run_full(std::integral_constant<int, AV_ACT_NONE>{}, yes);     // encoder q|k|v
         else if (full && !g.e.R && g.e.act == AV_ACT_GELU && hb) run_full(std::integral_constant<int, AV_ACT_GELU>{}, yes);     // Whisper fc1
@@ -1351,7 +1384,9 @@ extern "C" int avllm_debug_read_gemm_stamps(unsigned long long* host, int32_t n)
     return AV_OK;
 }
 #endif
-static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave, 8 256x256 4-wave persistent (lean epilogue only)
+static int g_gemm_variant = -1;     // 0 auto, 1 128x128, 2 256x128 ring, 5 256x256 16-wave, 6 256x256 16-wave persistent, 7 256x256 4-wave, 8 256x256 4-wave persistent (lean epilogue only), 9 256x128 persistent, two workgroups per CU (gemm_dp.hip; lean epilogue only)
+bool av_gemm_dp_ok(const avllm_gemm_desc* d);
+int av_gemm_dp(const avllm_gemm_desc* d, hipStream_t st, int dbg);
 extern "C" int avllm_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 bool av_prof_enabled();
 void av_prof_before(hipStream_t st);
@@ -1436,7 +1471,9 @@ int av_gemm(const avllm_gemm_desc* d, hipStream_t st) {
         // 7.7 + 1.67 for the 16-wave kernel, tools/gemm_ktile_sweep.py; small grids favour the 16-wave kernel a little longer)
         const bool auto_l = variant == 0 && !auto_h && d->K >= 16384;
         const bool lean_ok = wide_ok && d->alpha == 1.f && d->drop_p <= 0.f && d->g_in <= 0 && !e.out_f32 && d->r_mod <= 0;
-        if (d->M > 128 && (variant == 8 || auto_h) && lean_ok && d->K + d->K2 >= 128) {
+        if (d->M > 128 && variant == 9 && lean_ok && av_gemm_dp_ok(d)) {           // A/B variant, never chosen automatically (gemm_dp.hip: why)
+            AV_TRY(av_gemm_dp(d, st, g.dbg));
+        } else if (d->M > 128 && (variant == 8 || auto_h) && lean_ok && d->K + d->K2 >= 128) {
             if (!ds->attr_wp) {
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_wp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS));
                 AV_HIP(hipFuncSetAttribute((const void*)gemm_bf16_wp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS));

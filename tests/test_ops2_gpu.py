@@ -180,7 +180,7 @@ def test_attention_grouped_query(dev, dtype, impl, B, T, H, Hkv, hd):
         assert e < (3e-2 if dtype == torch.bfloat16 else 1e-5), (name, e)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7, 8, 9])
 def test_every_gemm_tiling_agrees(dev, variant):
     """All bf16 tilings compiled into the library (A/B variants included) compute the same epilogue-fused GEMM."""
     from avllm import lib as L
@@ -275,6 +275,39 @@ def test_gemm_persistent_kernel_many_tiles(dev, K, K2, act):
     acc = A[rows].float() @ B.float().t() + (A2[rows].float() @ B2.float().t() if K2 else 0.0) + bias.float()
     fn = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
     close(outs[8][rows], fn(acc) + x[rows].float(), 0.06, 2e-2, f"persistent gemm K={K}+{K2} {act}")
+
+
+@pytest.mark.parametrize("M,N", [(4300, 4360), (9000, 2304), (300, 136), (256, 128)])
+@pytest.mark.parametrize("K,K2,act,resid", [(128, 0, "none", False), (64, 64, "none", True), (192, 64, "quick_gelu", False), (320, 0, "gelu", False),
+                                            (768, 0, "none", True), (4096, 64, "none", True), (1024, 128, "none", False)])
+def test_gemm_two_workgroup_kernel_many_tiles(dev, M, N, K, K2, act, resid):
+    """The 256x128 persistent kernel that runs two workgroups per CU (csrc/gemm_dp.hip, variant 9): more tiles than workgroups (the three-stage
+    K-step ring runs across tile boundaries, with and without the 16 epilogue stores in flight), one and many macro steps, a LoRA segment of one
+    and two macro steps, ragged M / N edges and tiles smaller than a workgroup's, every lean epilogue form (plain, bias, bias + activation,
+    in-place residual with and without bias): bit-equal to the 16-wave kernel (same MFMA, same k order per accumulator, one rounding)."""
+    from avllm import lib as L
+    lib = L.load()
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=191), rnd(N, K, dtype=torch.bfloat16, seed=192, scale=K ** -0.5)
+    A2 = rnd(M, K2, dtype=torch.bfloat16, seed=193) if K2 else None
+    B2 = rnd(N, K2, dtype=torch.bfloat16, seed=194, scale=0.1) if K2 else None
+    x = rnd(M, N, dtype=torch.bfloat16, seed=196)
+    code = {"none": L.ACT_NONE, "gelu": L.ACT_GELU, "quick_gelu": L.ACT_QUICK_GELU}[act]
+    for bias in ((rnd(N, dtype=torch.bfloat16, seed=195), None) if act == "none" else (rnd(N, dtype=torch.bfloat16, seed=195),)):
+        outs = {}
+        try:
+            for variant in (9, 5):
+                lib.avllm_set_gemm_variant(variant)
+                o = x.clone()
+                ops.gemm(A, B, out=o, bias=bias, R=o if resid else None, A2=A2, B2=B2, act=code)
+                outs[variant] = o
+        finally:
+            lib.avllm_set_gemm_variant(0)
+        nd = int((outs[9] != outs[5]).sum())
+        assert nd == 0, f"{nd} of {M * N} values differ (bias={bias is not None}); first at {(outs[9] != outs[5]).nonzero()[:4].tolist()}"
+    rows = torch.cat([torch.randperm(M, device=dev)[:48], torch.tensor([0, min(255, M - 1), min(256, M - 1), M - 1], device=dev)])
+    acc = A[rows].float() @ B.float().t() + (A2[rows].float() @ B2.float().t() if K2 else 0.0) + (bias.float() if bias is not None else 0.0)      # the last bias tried
+    fn = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
+    close(outs[9][rows], fn(acc) + (x[rows].float() if resid else 0.0), 0.06, 2e-2, f"two-workgroup gemm K={K}+{K2} {act}")
 
 
 @pytest.mark.parametrize("M", [1, 2, 8, 16])
