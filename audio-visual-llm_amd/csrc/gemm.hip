@@ -103,6 +103,11 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& e, int m, int n
 
 using avg::epilogue_fast8; using avg::xcd_remap; using avg::tile_coords;
 
+// cache-policy bits of the operand DMA of the 4-wave kernels (experiment: tools/gemm_dma_policy.sh builds one library per policy); default none
+#ifndef AVLLM_DMA_POLICY
+#define AVLLM_DMA_POLICY ""
+#endif
+
 // ------------------------------------------------------------------------------------------ bf16
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
@@ -477,7 +482,7 @@ __device__ __forceinline__ void wgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][8
     constexpr int h = N >> 6, n = N & 63, I = n >> 3, J = n & 7;
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
 #define AV_W_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(base) : "memory")
+#define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" AVLLM_DMA_POLICY :: "s"(m0v), "v"(voff), "s"(base) : "memory")
     if constexpr (h == 0) {
         if constexpr (n < 16 && (n & 1)) AV_W_RD(FB[1][n >> 1], lb[BUF][1], (n >> 1) * 2048);
         if constexpr (n == 20) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -696,7 +701,7 @@ __device__ __forceinline__ void wpgemm_step(f32x4 (&acc)[8][8], bf16x8 (&FA)[2][
     if constexpr (FIRST && h == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(FB[h][J]), "v"(FA[h][I]));
 #define AV_W_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(base) : "memory")
+#define AV_W_LD(voff, base, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" AVLLM_DMA_POLICY :: "s"(m0v), "v"(voff), "s"(base) : "memory")
     // la/lb[1]: this lane's k-half-1 fragment address in the CURRENT buffer; la/lb[0]: k-half 0 in the OTHER buffer (next K-step)
     if constexpr (h == 0) {
         if constexpr (n < 16 && (n & 1)) AV_W_RD(FB[1][n >> 1], lb[1], WP_BOFF(n >> 1));
