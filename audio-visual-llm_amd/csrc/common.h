@@ -169,8 +169,14 @@ __host__ __device__ __forceinline__ uint32_t av_hash32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t av_drop_thr(float p) { return (uint32_t)(p * 65536.0f); }
 __host__ __device__ __forceinline__ float av_drop_scale(float p) { return 1.0f / (1.0f - (float)av_drop_thr(p) * (1.0f / 65536.0f)); }
 // hash word covering elements (2*pair, 2*pair+1)
+// (the inner avalanche depends on the pair index only through its high word: written so that the common case -- high word 0, fewer than 2^33
+// elements -- is av_hash32(seed), which is loop-invariant in every kernel and hoisted; one avalanche per pair instead of two.  Same value as
+// av_hash32(lo ^ av_hash32(seed + hi * 0x9E3779B9)) for every index.)
 __host__ __device__ __forceinline__ uint32_t av_pair_hash(uint32_t seed, unsigned long long pair) {
-    return av_hash32((uint32_t)pair ^ av_hash32(seed + (uint32_t)(pair >> 32) * 0x9E3779B9U));
+    const uint32_t hi = (uint32_t)(pair >> 32);
+    uint32_t inner = av_hash32(seed);
+    if (__builtin_expect(hi != 0u, 0)) inner = av_hash32(seed + hi * 0x9E3779B9U);
+    return av_hash32((uint32_t)pair ^ inner);
 }
 __host__ __device__ __forceinline__ bool av_keep(uint32_t seed, unsigned long long idx, float p) {
     const uint32_t h = av_pair_hash(seed, idx >> 1);
@@ -181,9 +187,20 @@ __host__ __device__ __forceinline__ bool av_keep(uint32_t seed, unsigned long lo
 __device__ __forceinline__ uint32_t av_seed(const uint32_t* seed_dev, uint32_t off) { return (seed_dev ? *seed_dev : 0u) + off; }
 // mask 8 consecutive elements starting at an EVEN index (4 hashes)
 __device__ __forceinline__ void av_mask8(float (&v)[8], uint32_t seed, unsigned long long idx0, uint32_t thr, float sc) {
+    const unsigned long long p0 = idx0 >> 1;
+    if (__builtin_expect(((p0 + 3) >> 32) == 0, 1)) {      // one test per 8 elements: below 2^33 elements the inner avalanche is av_hash32(seed), a scalar the compiler hoists
+        const uint32_t inner = av_hash32(seed);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t h = av_hash32(((uint32_t)p0 + q) ^ inner);
+            v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * sc : 0.f;
+            v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * sc : 0.f;
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t h = av_pair_hash(seed, (idx0 >> 1) + q);
+        const uint32_t h = av_pair_hash(seed, p0 + q);
         v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * sc : 0.f;
         v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * sc : 0.f;
     }
