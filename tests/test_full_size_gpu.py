@@ -1,0 +1,87 @@
+"""BASELINE.json configs[1] at its FULL size -- 16 clips x 125 frames, whisper-small + ViT-B/16 -> Llama-2-7B with LoRA r16, bf16, seeded random
+weights of the true shapes, the very workload bench.py times.  The CPU oracle needs ~20 s for ONE clip at this depth (test_pin_bf16_gpu.py runs
+that), so at the full batch parity goes through properties that do not depend on size:
+
+  * a sample's logits do not depend on its neighbours: clips 0..7 give the same logits, bit for bit, whatever clips 8..15 of the batch are.  Every
+    kernel of the path is row-independent -- a GEMM row's k order does not depend on the other rows of its tile, one (clip, head) per attention
+    workgroup, per-row normalisations, per-sample fusion and pooling; only the loss mean mixes samples.  (The batch SIZE stays 16: a smaller batch
+    takes other tilings for some launches, which sum k in another order; cuBLAS behaves the same way under the reference.)
+  * the loss is the token-weighted mean over samples and the LoRA gradient is linear in the per-token loss weights: with the labels of one half of
+    the batch masked out (-100) and then the other, the two losses / gradients combine to the full batch's (loss = sum of token losses / number of
+    label tokens, HF LlamaForCausalLM shift-and-mean; clip_whisper_model.py:586-619);
+  * a second identical call returns the same logits bit for bit (no state left in the workspaces between steps) and the same gradient up to the order
+    of the fp32 atomic adds that sum dA / dB over row slabs.
+LoRA dropout is off here (the counter-based mask of a step is a function of the step counter)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bars import bf16_depth_rel_l2, rel_l2  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def full_model(dev):
+    from avllm.model import ClipWhisperModel
+    torch.cuda.empty_cache()
+    m = ClipWhisperModel("meta-llama/Llama-2-7b-hf", "openai/whisper-small", "openai/clip-vit-base-patch16", device=dev, max_seq_len=512,
+                         precision="bf16", seed=0, synthetic_weights=True, lora_dropout=0.0).train()
+    eng = m.llm_engine
+    eng.lora_p.normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(9))      # B = 0 at initialisation would hide the adapters
+    eng.pack_lora()
+    yield m
+    del m
+    torch.cuda.empty_cache()
+
+
+def _batch(cfg, B, frames, dev, seed=1234):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    return synthetic_batch(cfg, B, frames, seed, dev)
+
+
+def _step(m, audio, video, labels, prompt):
+    eng = m.llm_engine
+    eng.lora_g.zero_()
+    out = m(audio=audio, video=video, prompt=prompt, labels=labels)
+    out["loss"].backward()
+    return float(out["loss"].detach()), out["logits"].clone(), eng.lora_g.clone()
+
+
+def test_full_size_batch_against_its_halves(dev, full_model):
+    m = full_model
+    B, frames = 16, 125
+    audio, video, labels, prompt = _batch(m.cfg, B, frames, dev)
+    loss, logits, grad = _step(m, audio, video, labels, prompt)
+    assert torch.isfinite(logits.float()).all() and loss == loss and float(grad.abs().max()) > 0
+    loss2, logits2, grad2 = _step(m, audio, video, labels, prompt)                          # idempotence: same call, same bits in the forward;
+    assert torch.equal(logits, logits2)                                                      # dA / dB are summed over row slabs with fp32 atomics: order only
+    assert rel_l2(grad2, grad) < 1e-6
+    # neighbours: other clips in slots 8..15
+    a2, v2, l2, p2 = _batch(m.cfg, B, frames, dev, seed=999)
+    a2[:8], v2[:8], l2[:8], p2[:8] = audio[:8], video[:8], labels[:8], prompt[:8]
+    _, logits_y, _ = _step(m, a2, v2, l2, p2)
+    nd = int((logits_y[:8] != logits[:8]).sum())
+    assert nd == 0, f"{nd} of {logits[:8].numel()} logits of clips 0..7 changed with clips 8..15"
+    assert not torch.equal(logits_y[8:], logits[8:])
+    del logits_y, a2, v2
+    # linearity in the label mask
+    pad = m.tokenizer.pad_token_id
+    ntok = (m._prep_labels(labels)[:, 1:] != -100).sum(1).float()                            # label tokens per sample after the shift
+    parts = []
+    for lo in (0, 8):
+        lab = labels.clone()
+        lab[(8 - lo):(16 - lo)] = pad                                                        # the OTHER half carries no loss
+        l_h, lg_h, g_h = _step(m, audio, video, lab, prompt)
+        assert torch.equal(lg_h, logits)                                                     # labels do not reach the logits
+        parts.append((float(ntok[lo:lo + 8].sum()), l_h, g_h))
+    n = sum(p[0] for p in parts)
+    assert n == float(ntok.sum()) and n > 100
+    assert abs(loss - sum(p[0] * p[1] for p in parts) / n) < 2e-5 * abs(loss)               # fp32 atomics of ~500 token losses: order only
+    gsum = sum(p[2] * (p[0] / n) for p in parts)
+    # The forward is the same in all three runs; in the backward every gradient row of a half-run is n / n_half times the full run's before each
+    # bf16 rounding (the loss normaliser differs), so the roundings of 32 layers differ: the backward's own share of tests/bars.py's depth estimate
+    # (1.13e-3 * sqrt(8 L) = 1.8e-2 at L = 32; measured 1.6e-2), bar = 2x
+    err = rel_l2(grad, gsum)
+    assert err < bf16_depth_rel_l2(32), f"LoRA gradient of the batch vs the token-weighted sum of its halves' gradients: rel-L2 {err:.2e}"
