@@ -85,3 +85,27 @@ def test_full_size_batch_against_its_halves(dev, full_model):
     # (1.13e-3 * sqrt(8 L) = 1.8e-2 at L = 32; measured 1.6e-2), bar = 2x
     err = rel_l2(grad, gsum)
     assert err < bf16_depth_rel_l2(32), f"LoRA gradient of the batch vs the token-weighted sum of its halves' gradients: rel-L2 {err:.2e}"
+
+
+def test_full_size_greedy_decode_does_not_depend_on_neighbours(dev, full_model):
+    """generate() at the bench's decode size (8 clips, 7B shapes, adapters attached -> the fused token step with the LoRA side term): the new
+    tokens of clips 0..3 are the same whatever clips 4..7 are, and the same on a second call.  With seeded random weights the logits are nearly flat,
+    so a single changed low-order bit anywhere in the step would change an argmax within a few tokens (clip_whisper_model.py:1240-1348)."""
+    m = full_model.eval()
+    try:
+        B, frames, new = 8, 125, 12
+        audio, video, _, prompt = _batch(m.cfg, B, frames, dev)
+        with torch.no_grad():
+            t1 = m.generate(audio=audio, video=video, prompt=prompt, max_new_tokens=new)
+            t2 = m.generate(audio=audio, video=video, prompt=prompt, max_new_tokens=new)
+            a2, v2, _, p2 = _batch(m.cfg, B, frames, dev, seed=4242)
+            a2[:4], v2[:4], p2[:4] = audio[:4], video[:4], prompt[:4]
+            t3 = m.generate(audio=a2, video=v2, prompt=p2, max_new_tokens=new)
+        assert t1.shape[0] == B and t1.shape[1] >= 1
+        assert torch.equal(t1, t2)
+        n = min(t1.shape[1], t3.shape[1])
+        assert torch.equal(t1[:4, :n], t3[:4, :n])
+        assert not torch.equal(t1[4:, :n], t3[4:, :n])
+        assert m.llm_engine.decode_is_fused(B)                     # the path under test is the 5-launch token step
+    finally:
+        full_model.train()
