@@ -59,7 +59,9 @@ typedef struct avllm_gemm_desc {
     const uint32_t* seed_dev;           /* optional DEVICE word added to drop_seed / a_drop_seed at run time (see avllm_step_state) */
 } avllm_gemm_desc;
 int avllm_gemm(const avllm_gemm_desc* d, void* stream);
-/* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT) */
+/* A/B testing only: force one bf16 tiling (0 = automatic choice; same values as env AVLLM_GEMM_VARIANT): 1 = 128x128, 2 = 256x128 ring, 5 / 6 = 256x256
+ * with 16 waves (one-shot / persistent), 7 / 8 = 256x256 with 4 waves (one-shot / persistent: the default for every lean-epilogue call on a chip-filling
+ * grid), 9 = 256x128 persistent with two workgroups per CU (csrc/gemm_dp.hip).  A variant that cannot take a call leaves it to the automatic choice. */
 int avllm_set_gemm_variant(int v);
 /* A/B testing only: the library's experiment switches live in ONE table that is filled once per process from the environment
  * (AVLLM_<NAME>) and changed afterwards only through this call.  Names: "DECODE_FUSED" (0 = general 10-launch decode layer),
