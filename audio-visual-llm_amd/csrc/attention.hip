@@ -323,6 +323,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    asm volatile("" : "+v"(ones));           // opaque: left as a constant it was re-materialised with four v_mov before every row-sum MFMA (28 per query block)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, g = lane >> 4;
     // The kernel is bound by its instruction stream (profiles/r02_experiments.txt), so the per-score work is trimmed: v_maximum3_f32 through
