@@ -273,7 +273,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
 // image osc of an avllm_gemm_f8 A operand: the fp8 out-projection reads it directly and the [M, d] bf16 attention output never exists
 // (1.6 GB written + read back per ViT-L/14 layer at 750 frames x 4 clips).  A 32-feature block of a row = the 4 lanes of one row in the
 // write-out below; the scale byte of global row m, column block cb sits at ((((cb >> 2) * RB + (m >> 6)) * 4 + (cb & 3)) * 16 + (m & 15)) * 4 + ((m >> 4) & 3).
-template <int NKB, int NW, bool QOUT>
+// FULLK: the sequence uses every key block (nkb == NKB, e.g. CLIP's 197 tokens = 13 blocks), decided at launch: as a run-time branch the
+// compiler hoisted the OTHER form's per-block "is this key inside T" masks above it (52 compares, 96 v_writelane of spilled scalar masks:
+// as many instructions as a whole query block, paid by every wave).
+template <int NKB, int NW, bool QOUT, bool FULLK>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int T, int H, long ldq, long ldk,
                                                           long ldv, long ldo, float scale_log2e, int G, uint8_t* __restrict__ oq, long ldoq,
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_short(const bf16* __restrict
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
-    if (nkb == NKB) {
+    if constexpr (FULLK) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi)
             if (w + NW * qi < NKB) qblock(qi, std::true_type{});
@@ -457,15 +460,19 @@ int launch_fwd_short(const void* q, const void* k, const void* v, void* o, float
     int dev = 0;
     AV_HIP(hipGetDevice(&dev));
     if (!attr[dev & 63]) {
-        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        AV_HIP(hipFuncSetAttribute((const void*)attn_fwd_short<NKB, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr[dev & 63] = true;
     }
     const int RBo = (int)(((long)B * T + 255) / 256 * 4);            // mx_groups(rows) of fp8.hip: 64-row groups, padded to whole 256-row tiles
-    if (oq) hipLaunchKernelGGL((attn_fwd_short<NKB, NW, true>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse,
-                               T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G, (uint8_t*)oq, ldoq, (uint8_t*)osc, RBo);
-    else hipLaunchKernelGGL((attn_fwd_short<NKB, NW, false>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse,
-                            T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G, nullptr, 0, nullptr, 0);
+    const bool fullk = ((T + 15) >> 4) == NKB;
+#define AV_SHORT(QV, FV, OQ, LDOQ, OSC, RB) hipLaunchKernelGGL((attn_fwd_short<NKB, NW, QV, FV>), dim3(H, B), dim3(NW * 64), LDS, st, (const bf16*)q, (const bf16*)k, \
+        (const bf16*)v, (bf16*)o, lse, T, H, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, G, OQ, LDOQ, OSC, RB)
+    if (oq) { if (fullk) AV_SHORT(true, true, (uint8_t*)oq, ldoq, (uint8_t*)osc, RBo); else AV_SHORT(true, false, (uint8_t*)oq, ldoq, (uint8_t*)osc, RBo); }
+    else { if (fullk) AV_SHORT(false, true, nullptr, 0, nullptr, 0); else AV_SHORT(false, false, nullptr, 0, nullptr, 0); }
+#undef AV_SHORT
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
