@@ -109,3 +109,38 @@ def test_full_size_greedy_decode_does_not_depend_on_neighbours(dev, full_model):
         assert m.llm_engine.decode_is_fused(B)                     # the path under test is the 5-launch token step
     finally:
         full_model.train()
+
+
+def test_full_size_config5_fp8_step_properties(dev, full_model):
+    """BASELINE configs[4] at the size bench.py's `variants.config5_fp8` leg runs it (whisper-large-v3 + ViT-L/14 -> Mistral-7B geometry, 4 clips x 750
+    frames, block-scaled fp8 on the frozen forward projections; parity unpinned for the fp8 rule itself -- the reference has no fp8): the same
+    size-independent properties.  MX scales are per 32-element block of ONE row (layout 0 only groups rows for addressing), so a clip's logits must not
+    depend on its neighbours here either; and the fp8 and the bf16 arithmetic of the same model must agree to the depth form of the fp8 bar (tests/bars.py fp8_depth_rel_l2)."""
+    from avllm.model import ClipWhisperModel
+    from bars import FP8_LOSS_ABS, fp8_depth_rel_l2
+    del full_model                                             # (fixture order: the 7B bf16 model of this module stays alive; this one is built beside it)
+    m = ClipWhisperModel("mistralai/Mistral-7B-v0.1", "openai/whisper-large-v3", "openai/clip-vit-large-patch14", device=dev, max_seq_len=512,
+                         precision="fp8", seed=0, synthetic_weights=True, lora_dropout=0.0).train()
+    eng = m.llm_engine
+    eng.lora_p.normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(9))
+    eng.pack_lora()
+    B, frames = 4, 750
+    audio, video, labels, prompt = _batch(m.cfg, B, frames, dev, seed=4321)
+    loss, logits, grad = _step(m, audio, video, labels, prompt)
+    assert torch.isfinite(logits.float()).all() and loss == loss and float(grad.abs().max()) > 0
+    _, logits2, _ = _step(m, audio, video, labels, prompt)
+    assert torch.equal(logits, logits2)
+    a2, v2, l2, p2 = _batch(m.cfg, B, frames, dev, seed=77)
+    a2[:2], v2[:2], l2[:2], p2[:2] = audio[:2], video[:2], labels[:2], prompt[:2]
+    _, logits_y, _ = _step(m, a2, v2, l2, p2)
+    nd = int((logits_y[:2] != logits[:2]).sum())
+    assert nd == 0, f"{nd} of {logits[:2].numel()} logits of clips 0..1 changed with clips 2..3 (fp8)"
+    assert not torch.equal(logits_y[2:], logits[2:])
+    del logits_y, a2, v2
+    for e in (m.whisper_engine, m.clip_engine, m.llm_engine):
+        e.desc.fp8 = 0
+    loss_b, logits_b, _ = _step(m, audio, video, labels, prompt)
+    err = rel_l2(logits, logits_b)
+    assert err < fp8_depth_rel_l2(m.cfg.llama.layers) and abs(loss - loss_b) < FP8_LOSS_ABS, (err, loss, loss_b)      # tests/bars.py: 0.215 at 32 layers
+    del m
+    torch.cuda.empty_cache()
