@@ -33,7 +33,7 @@ __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8
 __device__ __forceinline__ float max3f(float a, float x, float y) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, x), y); }
 
 template <int HD, int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mfma(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                          const bf16* __restrict__ v, bf16* __restrict__ o, float* __restrict__ lse,
                                                          int Tq, int Tk, int H, long ldq, long ldk, long ldv, long ldo,
                                                          float scale_log2e, int G) {
@@ -45,8 +45,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
     // 75 KiB -> two workgroups per CU) and the key loop runs without any further barrier; otherwise 64-key tiles.
     constexpr bool ONESHOT = (HD == 64 && NW == 7 && !CAUSAL);
     constexpr int LROWS = ONESHOT ? 224 : 64;
-    __shared__ __attribute__((aligned(16))) char k_lds[LROWS * KS];
-    __shared__ __attribute__((aligned(16))) char v_lds[LROWS * VS];
+    // DB (long sequences at head_dim 64: Whisper, T = 1500, 24 tiles): the K/V tile buffers are doubled, tile t+1 is parked in the other buffer
+    // right after the barrier that opens iteration t and ONE barrier per tile remains (two with a single buffer: "previous tile consumed" and
+    // "this tile stored").  Two buffers at head_dim 128 would pass the 64 KiB of static LDS.
+    constexpr bool DB = (HD == 64 && NW == 4);
+    constexpr int NBUF = DB ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char k_lds_[NBUF * LROWS * KS];
+    __shared__ __attribute__((aligned(16))) char v_lds_[NBUF * LROWS * VS];
+    char* k_lds = k_lds_;
+    char* v_lds = v_lds_;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -117,10 +124,27 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const bf16* __restrict_
         }
         __syncthreads();
     }
+    auto park = [&](int buf) {                      // the staged registers -> tile buffer buf
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NT;
+            if (c < 64 * CPR) {
+                const int row = c / CPR, ch = c % CPR;
+                *(u32x4*)(k_lds_ + buf * LROWS * KS + row * KS + ch * 16) = kreg[i];
+                *(u32x4*)(v_lds_ + buf * LROWS * VS + row * VS + ch * 16) = vreg[i];
+            }
+        }
+    };
     if (PREFETCH) prefetch(0);
+    if (DB) { park(0); if (64 < k_end) prefetch(64); }
     for (int kb = 0; kb < k_end; kb += 64) {
         const int lrow0 = ONESHOT ? kb : 0;        // first LDS row of this 64-key step
-        if (!ONESHOT) {
+        if (DB) {
+            const int buf = (kb >> 6) & 1;
+            __syncthreads();                       // tile kb/64 is stored (previous iteration) and the other buffer has been read by everybody
+            if (kb + 64 < k_end) { park(buf ^ 1); if (kb + 128 < k_end) prefetch(kb + 128); }
+            k_lds = k_lds_ + buf * LROWS * KS; v_lds = v_lds_ + buf * LROWS * VS;
+        } else if (!ONESHOT) {
             if (!PREFETCH) prefetch(kb);
             __syncthreads();                       // previous tile fully consumed
 #pragma unroll
